@@ -1,0 +1,135 @@
+/*
+ * rt_is.h — C ABI of librt_is.so, the MI355X (gfx950) implementation of Roundtrip's
+ * importance-sampling (IS) density evaluation path.
+ *
+ * The reference has no FFI for this path: it is a Python method on the model object
+ * (`RoundtripModel.estimate_py_with_IS`, /root/reference/main_density_est.py:266-348; v2 twin
+ * `Roundtrip.estimate_px_with_IS`, /root/reference/src/pyroundtrip/roundtrip.py:229-310).  The entry
+ * points below are what a ctypes binding inside that method would call; each one cites the reference
+ * lines it replaces.  The binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = RT_OK, otherwise an RT_E* code; the text of the last
+ *     failure on a context is available from rt_last_error().  No C++ exception crosses this boundary.
+ *   - all matrices are dense, row-major, little-endian.  Dense-layer weights are stored [in, out]
+ *     (the TensorFlow convention: out = in @ W + b).
+ *   - names follow the v1 reference: y = data point (dim dy), x = latent (dim dx), G : x -> y is MLP 0,
+ *     H : y -> x is MLP 1.  (v2 spells the same things x / z / g_net / e_net.)
+ *   - a context is bound to one HIP device and owns one stream.  It is not re-entrant; different
+ *     contexts may be used from different threads.
+ *   - pointers are HOST pointers unless the function name ends in `_dev`.
+ */
+#ifndef RT_IS_H
+#define RT_IS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK            0
+#define RT_EINVAL        1   /* bad argument (shape, NULL pointer, unsupported value) */
+#define RT_EHIP          2   /* a HIP runtime call failed */
+#define RT_ENOTSET       3   /* the MLP needed by the call has not been set */
+#define RT_EUNSUPPORTED  4   /* shape outside what the kernels handle */
+#define RT_ENOMEM        5
+
+#define RT_MLP_G 0           /* generator  G: x (dx) -> y (dy)  : g_net, main_density_est.py:447 */
+#define RT_MLP_H 1           /* encoder    H: y (dy) -> x (dx)  : h_net / e_net, main_density_est.py:448 */
+
+#define RT_MAX_LAYERS 24
+
+typedef struct rt_ctx rt_ctx;
+
+typedef struct rt_counters {
+    double   kernel_ms;      /* sum of the fused IS kernel's durations (HIP events on the context's stream) */
+    double   flops;          /* algorithmic flops of those launches: N*S*2*sum(in_l*out_l) over G's layers, unpadded */
+    uint64_t launches;       /* number of fused IS kernel launches summed */
+    uint64_t sample_evals;   /* N*S summed */
+} rt_counters;
+
+/* Creates a context on HIP device `device` (replaces nothing in the reference: TF session creation,
+ * main_density_est.py:114-121, is the nearest analogue). */
+int rt_ctx_create(int device, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+
+/* Text of the last error on this context ("" if none).  ctx == NULL returns the last creation error. */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Uploads one MLP (replaces the weights `tf.train.Saver.restore` puts into the graph,
+ * main_density_est.py:397-411, and the layer structure of model.Generator.__call__, model.py:61-88 /
+ * BaseFullyConnectedNet, src/pyroundtrip/model.py:17-25).
+ *   which     RT_MLP_G or RT_MLP_H
+ *   n_layers  number of dense layers (hidden layers + the linear output layer), 2..RT_MAX_LAYERS
+ *   dims      n_layers+1 ints: dims[0] = input dim, dims[l+1] = width of layer l's output
+ *   W[l]      dims[l] x dims[l+1] floats, row-major;  b[l]: dims[l+1] floats
+ *   lrelu_alpha  leaky-ReLU slope applied after every layer but the last (0.2 in the reference,
+ *             model.py:5-6); must be in [0, 1].
+ */
+int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims,
+               const float* const* W, const float* const* b, float lrelu_alpha);
+
+/* out[n,:] = MLP_which(in[n,:]) for n < N, float32.  Replaces predict_y / predict_x
+ * (main_density_est.py:222-234 / 237-249; v2: self.g_net(...) / self.e_net(...), roundtrip.py:249,283). */
+int rt_mlp_forward(rt_ctx* ctx, int which, const float* in, int64_t N, float* out);
+
+/* xhat = H(y): rt_mlp_forward(ctx, RT_MLP_H, ...) under the name the estimator uses
+ * (main_density_est.py:320). */
+int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);
+
+/* Importance-sampling estimate of p(y[n]) for n < N  (main_density_est.py:321-345).
+ *   y      N x dy float64 query points          xhat   N x dx float32 proposal centres H(y)
+ *   y_index_base  global index of y[0]: sample i of query point n is drawn from the counter-based
+ *          generator at (seed, y_index_base + n, i), so a sharded evaluation is bit-identical to an
+ *          unsharded one
+ *   S      sample_size       sd_y, scale, df   as in the reference (df: main_density_est.py:41)
+ *   log_flag  1: out = log p(y)   0: out = p(y)  (reference `log=`; :339-345)
+ *   out    N float64
+ * Proposal (replaces sample_from_qx, :310-318): x_i = xhat + scale * z / sqrt(chi2_df / df), z ~ N(0,I).
+ * Score (replaces py_given_x :278-290 and w_likelihood_ratio :292-307), float64:
+ *   v_i = -dy*log(sqrt(2pi)*sd_y) - |y - G(x_i)|^2 / (2 sd_y^2) - dx*log(sqrt(2pi)) - |x_i|^2/2
+ *         - sum_d t.logpdf(xhat_d - x_id, df, 0, scale)
+ * Reduction (:339-345): log( sum_i exp(v_i) ) - log(S).
+ * Samples whose score is not finite carry weight 0.
+ */
+int rt_is_estimate(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                   int64_t S, double sd_y, double scale, double df, uint64_t seed, int log_flag,
+                   double* out);
+
+/* Same, with the proposal samples supplied by the caller instead of drawn on the GPU (parity mode):
+ *   x_samples  N x S x dx float64 — what sample_from_qx (:310-318) returned for each query point.
+ * G sees (float)x (the reference feeds a float32 placeholder, :232), the score uses the float64 x. */
+int rt_is_estimate_given_samples(rt_ctx* ctx, const double* y, const float* xhat,
+                                 const double* x_samples, int64_t N, int64_t S, double sd_y,
+                                 double scale, double df, int log_flag, double* out);
+
+/* Writes the float32 proposal samples rt_is_estimate would use: x_samples is N x S x dx.
+ * (Exposes sample_from_qx, :310-318, for tests.) */
+int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,
+                    double scale, double df, uint64_t seed, float* x_samples);
+
+/* Device-resident variant of rt_is_estimate: y_dev, xhat_dev, out_dev are DEVICE pointers on the
+ * context's device.  Enqueues on the context's stream and returns without waiting; call rt_sync()
+ * before reading out_dev from another stream or the host. */
+int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
+                       int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
+                       uint64_t seed, int log_flag, double* out_dev);
+
+/* Device-resident rt_mlp_forward (in_dev/out_dev are device pointers); asynchronous like the above. */
+int rt_mlp_forward_dev(rt_ctx* ctx, int which, const float* in_dev, int64_t N, float* out_dev);
+
+/* Waits for everything enqueued on the context's stream. */
+int rt_sync(rt_ctx* ctx);
+
+/* Kernel-time / flop counters accumulated since the last rt_reset_counters (waits for the stream). */
+int rt_get_counters(rt_ctx* ctx, rt_counters* out);
+int rt_reset_counters(rt_ctx* ctx);
+
+/* Device facts the host side needs for work partitioning. */
+int rt_device_cu_count(rt_ctx* ctx, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_IS_H */

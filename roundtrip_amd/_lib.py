@@ -1,0 +1,202 @@
+"""ctypes binding of librt_is.so (include/rt_is.h): the only compute path of this package.
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_is.so")
+
+RT_MLP_G = 0
+RT_MLP_H = 1
+
+# every symbol include/rt_is.h declares (tests check the library exports each one)
+SYMBOLS = (
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_encode",
+    "rt_is_estimate", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
+    "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
+)
+
+
+class RtCounters(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("flops", C.c_double), ("launches", C.c_uint64),
+                ("sample_evals", C.c_uint64)]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads librt_is.so (once).  Raises ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  roundtrip_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    fpp = C.POINTER(C.POINTER(C.c_float))
+    lib.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rt_ctx_destroy.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_set_mlp.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int32), fpp, fpp, C.c_float]
+    lib.rt_mlp_forward.argtypes = [vp, C.c_int, vp, i64, vp]
+    lib.rt_encode.argtypes = [vp, vp, i64, vp]
+    lib.rt_is_estimate.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, C.c_int, vp]
+    lib.rt_is_estimate_given_samples.argtypes = [vp, vp, vp, vp, i64, i64, dbl, dbl, dbl, C.c_int, vp]
+    lib.rt_draw_samples.argtypes = [vp, vp, i64, i64, i64, dbl, dbl, C.c_uint64, vp]
+    lib.rt_is_estimate_dev.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, C.c_int, vp]
+    lib.rt_mlp_forward_dev.argtypes = [vp, C.c_int, vp, i64, vp]
+    lib.rt_sync.argtypes = [vp]
+    lib.rt_get_counters.argtypes = [vp, C.POINTER(RtCounters)]
+    lib.rt_reset_counters.argtypes = [vp]
+    lib.rt_device_cu_count.argtypes = [vp, C.POINTER(C.c_int)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name != "rt_last_error":
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class Engine(object):
+    """One rt_ctx: a HIP device, a stream, and the uploaded G / H networks."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.rt_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise RtError("rt_ctx_create(device=%d) failed (%d): %s"
+                          % (device, rc, self._lib.rt_last_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+        self.dims = {}
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rt_ctx_destroy(h)
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise RtError("librt_is error %d: %s" % (rc, self._lib.rt_last_error(self._h).decode()))
+
+    def set_mlp(self, which, weights, biases, alpha=0.2):
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, dtype=np.float32).reshape(-1) for b in biases]
+        if len(ws) != len(bs) or not ws:
+            raise ValueError("weights and biases must be non-empty lists of equal length")
+        dims = [ws[0].shape[0]]
+        for w, b in zip(ws, bs):
+            if w.ndim != 2 or w.shape[0] != dims[-1] or b.shape[0] != w.shape[1]:
+                raise ValueError("layer shapes do not chain: %r / %r after width %d" % (w.shape, b.shape, dims[-1]))
+            dims.append(w.shape[1])
+        n = len(ws)
+        fp = C.POINTER(C.c_float)
+        W = (fp * n)(*[w.ctypes.data_as(fp) for w in ws])
+        B = (fp * n)(*[b.ctypes.data_as(fp) for b in bs])
+        D = (C.c_int32 * (n + 1))(*dims)
+        self._chk(self._lib.rt_set_mlp(self._h, int(which), n, D, W, B, float(alpha)))
+        self.dims[int(which)] = dims
+
+    def mlp_forward(self, which, x):
+        dims = self.dims.get(int(which))
+        if dims is None:
+            raise RtError("MLP %d has not been set" % which)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != dims[0]:
+            raise ValueError("expected shape (N, %d), got %r" % (dims[0], x.shape))
+        out = np.empty((x.shape[0], dims[-1]), dtype=np.float32)
+        self._chk(self._lib.rt_mlp_forward(self._h, int(which), x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def _g_dims(self):
+        dims = self.dims.get(RT_MLP_G)
+        if dims is None:
+            raise RtError("G has not been set")
+        return dims[0], dims[-1]
+
+    def is_estimate(self, y, xhat, sample_size, sd_y, scale, df=1.0, seed=0, log=True, y_index_base=0):
+        dx, dy = self._g_dims()
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != dy:
+            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
+        N = y.shape[0]
+        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
+        if xhat.shape != (N, dx):
+            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        out = np.empty(N, dtype=np.float64)
+        self._chk(self._lib.rt_is_estimate(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
+                                           int(sample_size), float(sd_y), float(scale), float(df),
+                                           int(seed), int(bool(log)), out.ctypes.data))
+        return out
+
+    def is_estimate_given_samples(self, y, xhat, x_samples, sd_y, scale, df=1.0, log=True):
+        dx, dy = self._g_dims()
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != dy:
+            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
+        N = y.shape[0]
+        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
+        if xhat.shape != (N, dx):
+            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        xs = np.ascontiguousarray(x_samples, dtype=np.float64)
+        if xs.ndim != 3 or xs.shape[0] != N or xs.shape[2] != dx or xs.shape[1] < 1:
+            raise ValueError("expected x_samples of shape (%d, S, %d), got %r" % (N, dx, xs.shape))
+        out = np.empty(N, dtype=np.float64)
+        self._chk(self._lib.rt_is_estimate_given_samples(self._h, y.ctypes.data, xhat.ctypes.data,
+                                                         xs.ctypes.data, N, xs.shape[1], float(sd_y),
+                                                         float(scale), float(df), int(bool(log)),
+                                                         out.ctypes.data))
+        return out
+
+    def draw_samples(self, xhat, sample_size, scale, df=1.0, seed=0, y_index_base=0):
+        dx, _ = self._g_dims()
+        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
+        if xhat.ndim != 2 or xhat.shape[1] != dx:
+            raise ValueError("expected xhat of shape (N, %d), got %r" % (dx, xhat.shape))
+        xs = np.empty((xhat.shape[0], int(sample_size), dx), dtype=np.float32)
+        self._chk(self._lib.rt_draw_samples(self._h, xhat.ctypes.data, xhat.shape[0], int(y_index_base),
+                                            int(sample_size), float(scale), float(df), int(seed),
+                                            xs.ctypes.data))
+        return xs
+
+    # ---- device-resident entry points (pointers are raw device addresses, e.g. torch .data_ptr()) ----
+    def is_estimate_dev(self, y_ptr, xhat_ptr, N, sample_size, sd_y, scale, out_ptr, df=1.0, seed=0,
+                        log=True, y_index_base=0):
+        self._chk(self._lib.rt_is_estimate_dev(self._h, y_ptr, xhat_ptr, int(N), int(y_index_base),
+                                               int(sample_size), float(sd_y), float(scale), float(df),
+                                               int(seed), int(bool(log)), out_ptr))
+
+    def mlp_forward_dev(self, which, in_ptr, N, out_ptr):
+        self._chk(self._lib.rt_mlp_forward_dev(self._h, int(which), in_ptr, int(N), out_ptr))
+
+    def sync(self):
+        self._chk(self._lib.rt_sync(self._h))
+
+    def counters(self):
+        c = RtCounters()
+        self._chk(self._lib.rt_get_counters(self._h, C.byref(c)))
+        return {"kernel_ms": c.kernel_ms, "flops": c.flops, "launches": int(c.launches),
+                "sample_evals": int(c.sample_evals)}
+
+    def reset_counters(self):
+        self._chk(self._lib.rt_reset_counters(self._h))
+
+    def cu_count(self):
+        n = C.c_int()
+        self._chk(self._lib.rt_device_cu_count(self._h, C.byref(n)))
+        return n.value

@@ -1,0 +1,951 @@
+// rt_is.hip — gfx950 (MI355X / CDNA4) kernels and C ABI for Roundtrip's importance-sampling density
+// evaluation (reference: /root/reference/main_density_est.py:266-348, src/pyroundtrip/roundtrip.py:229-310).
+//
+// Design (details and numbers: DESIGN.md):
+//   * one persistent 256-thread workgroup per CU; a workgroup pushes 64 proposal samples at a time
+//     ("pass") through all of G's dense layers without leaving the CU;
+//   * layer GEMMs run on v_mfma_f32_32x32x2_f32 in the transposed form  H_out^T = W^T · H_in^T : output
+//     features are MFMA rows, samples are MFMA columns (lanes).  Wave w owns HID/4 output features x 64
+//     samples (HID/128 x 2 accumulator tiles);
+//   * activations live in LDS (HID x 64 fp32) in a [k/8][sample][8] image that is both the B-operand
+//     read format (ds_read_b128 = four k-steps) and the accumulator write format (ds_write_b128);
+//   * weights are pre-packed on the host into per-lane A-operand order, so every wave streams ITS OWN
+//     feature slice straight global(L2) -> VGPR with 16-byte coalesced loads, software-pipelined one
+//     k-group ahead; no LDS staging and no barrier inside a layer's K loop;
+//   * the proposal sampler (Philox4x32-10 + Box-Muller), the Gaussian / Student-t scoring (fp64) and the
+//     online log-sum-exp are fused around the MLP, so nothing per-sample ever reaches HBM.
+//
+// Nothing here falls back to the CPU: every entry point launches these kernels or returns an error.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "../../include/rt_is.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int MS = 64;          // samples per workgroup pass
+constexpr int NTHREADS = 256;   // 4 waves, one per SIMD
+constexpr int MAX_IN = 64;      // max input dim of a fused MLP (dx for G)
+constexpr int MAX_OUT = 128;    // max output dim of a fused MLP (dy for G)
+
+struct MlpArgs {
+    const float* wp[RT_MAX_LAYERS];  // packed weights, see pack_layer()
+    const float* bp[RT_MAX_LAYERS];  // biases padded to a multiple of 32
+    int n_layers;
+    int in_dim;
+    int out_dim;
+    int k0;       // in_dim rounded up to a multiple of 8
+    int nt_out;   // ceil(out_dim / 32)
+    float alpha;
+};
+
+// ----------------------------------------------------------------------------------------------
+// LDS activation image.  Row-block kg holds k = 8kg .. 8kg+7 for the 64 samples of the pass:
+//   byte offset of (kg, sample s, half hh in {0,1}, element e in 0..3) =
+//       ((kg*64 + s)*2 + (hh ^ swz(s)))*16 + 4e          holding k = 8kg + 4hh + e
+// swz() makes the ds_read_b128 of a 32-lane half (stride 32 B between samples) and the
+// ds_write_b128 of the epilogue conflict-free (bank rules: MI355X_MICROARCH.md, LDS section).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ int act_swz(int s) { return ((s >> 3) ^ (s >> 2)) & 1; }
+__device__ __forceinline__ int act_off(int kg, int s, int hh) {
+    return ((kg * 64 + s) * 2 + (hh ^ act_swz(s))) * 16;
+}
+
+// ----------------------------------------------------------------------------------------------
+// One k-group (8 k values = 4 MFMA k-steps of 2) for NFT feature tiles x 2 sample tiles.
+// MFMA 32x32x2 operand maps (cdna_hip_programming.md §3): lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// here lane half h at step e handles k = 8kg + 4h + e (any k order is a valid sum).
+// ----------------------------------------------------------------------------------------------
+template <int NFT>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][2], const f32x4 (&a)[NFT],
+                                           const f32x4 (&b)[2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][e], b[st][e], acc[ft][st], 0, 0, 0);
+}
+
+// acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
+//   wl   : this lane's packed A operands for (kg = first, ft = 0); stride between kg = ftt*64 f32x4,
+//          between feature tiles = 64 f32x4
+//   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 2048 B,
+//          sample tile stride 1024 B
+// Weights and activations for k-group kg+1 are loaded while k-group kg's 8*NFT MFMAs issue.
+template <int NFT>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][2], const f32x4* __restrict__ wl,
+                                          int ftt, int nkg, const char* bl) {
+    f32x4 a0[NFT], a1[NFT], b0[2], b1[2];
+    const int wstride = ftt * 64;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) a0[ft] = wl[ft * 64];
+    b0[0] = *(const f32x4*)(bl);
+    b0[1] = *(const f32x4*)(bl + 1024);
+    int kg = 0;
+#pragma unroll 1
+    for (; kg + 2 <= nkg; kg += 2) {
+        {
+            const f32x4* w1 = wl + (size_t)(kg + 1) * wstride;
+            const char* l1 = bl + (kg + 1) * 2048;
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) a1[ft] = w1[ft * 64];
+            b1[0] = *(const f32x4*)(l1);
+            b1[1] = *(const f32x4*)(l1 + 1024);
+        }
+        mfma_group<NFT>(acc, a0, b0);
+        if (kg + 2 < nkg) {
+            const f32x4* w2 = wl + (size_t)(kg + 2) * wstride;
+            const char* l2 = bl + (kg + 2) * 2048;
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) a0[ft] = w2[ft * 64];
+            b0[0] = *(const f32x4*)(l2);
+            b0[1] = *(const f32x4*)(l2 + 1024);
+        }
+        mfma_group<NFT>(acc, a1, b1);
+    }
+    if (kg < nkg) mfma_group<NFT>(acc, a0, b0);
+}
+
+// Hidden-layer epilogue: act = lrelu(acc + bias), written in the next layer's B-operand image.
+// C/D map of the 32x32 MFMA: lane (h, j): column j = sample; register r = row (r&3) + 8(r>>2) + 4h = feature.
+// Registers 4q..4q+3 of tile (FT, st) are features 32FT + 8q + 4h + (0..3) = next-layer k-group 4FT+q, half h.
+template <int NFT>
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][2], const float* __restrict__ bias,
+                                          float alpha, char* act, int wave, int lane) {
+    const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        const int FT = wave * NFT + ft;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(bias + 32 * FT + 8 * q + 4 * h);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[ft][st][4 * q + e] + bv[e];
+                    v[e] = fmaxf(t, alpha * t);
+                }
+                *(f32x4*)(act + act_off(4 * FT + q, 32 * st + j, h)) = v;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
+    }
+}
+
+// Output layer for NT feature tiles, K split over the four waves; partial sums go to
+// part[(wave*out_dim + d)*64 + s] (floats, aliases the activation image).
+template <int NT>
+__device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, float* part, int wave,
+                                           int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
+    const f32x4* wl = (const f32x4*)m.wp[m.n_layers - 1] + (size_t)(wave * kq) * NT * 64 + lane;
+    gemm_tile<NT>(acc, wl, NT, kq, act + act_off(wave * kq, j, h));
+    __syncthreads();   // every wave is done reading the activation image
+    const int od = m.out_dim;
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (d < od) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) part[(wave * od + d) * 64 + 32 * st + j] = acc[ft][st][r];
+            }
+        }
+    __syncthreads();
+}
+
+// Runs the MLP on the 64 samples whose (padded) inputs sit in the x0 image.  On return
+// part[(w*out_dim + d)*64 + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
+// (bias not yet added).  Must be called by all 256 threads.
+template <int HID>
+__device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane) {
+    constexpr int NFT = HID / 128;
+    constexpr int FTT = HID / 32;
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[NFT][2];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
+
+    gemm_tile<NFT>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
+                   x0 + act_off(0, j, h));
+    const int nhid = m.n_layers - 1;
+    for (int l = 0; l < nhid; ++l) {
+        if (l > 0) __syncthreads();   // all waves finished reading layer l's input
+        store_act<NFT>(acc, m.bp[l], m.alpha, act, wave, lane);
+        __syncthreads();
+        if (l + 1 < nhid)
+            gemm_tile<NFT>(acc, (const f32x4*)m.wp[l + 1] + (wave * NFT) * 64 + lane, FTT, HID / 8,
+                           act + act_off(0, j, h));
+    }
+    float* part = (float*)act;
+    switch (m.nt_out) {
+        case 1: last_layer<1>(m, HID / 32, act, part, wave, lane); break;
+        case 2: last_layer<2>(m, HID / 32, act, part, wave, lane); break;
+        case 3: last_layer<3>(m, HID / 32, act, part, wave, lane); break;
+        default: last_layer<4>(m, HID / 32, act, part, wave, lane); break;
+    }
+}
+
+__device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
+    const int od = m.out_dim;
+    const float p0 = part[(0 * od + d) * 64 + s], p1 = part[(1 * od + d) * 64 + s];
+    const float p2 = part[(2 * od + d) * 64 + s], p3 = part[(3 * od + d) * 64 + s];
+    return ((p0 + p1) + p2) + p3 + m.bp[m.n_layers - 1][d];
+}
+
+// ----------------------------------------------------------------------------------------------
+// Proposal sampler: Philox4x32-10, counter = (sample index, call index, y index lo, y index hi),
+// key = seed.  Call c yields standard normals g[4c .. 4c+3] by two Box-Muller transforms.
+// Integer df = ndf: chi2 = g[0]^2 + .. + g[ndf-1]^2, x_d = xhat_d + scale * g[ndf+d] / sqrt(chi2/df).
+// Non-integer df: chi2 = 2*Gamma(df/2) by Marsaglia-Tsang on call indices >= 0x40000000; x_d uses g[d].
+// ----------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {   // (0,1), 24 bits, never 0 or 1
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u01(b), &sn, &cs);
+    n0 = r * cs;
+    n1 = r * sn;
+}
+
+struct SamplerArgs {
+    uint32_t seed_lo, seed_hi;
+    int ndf;        // df if it is an integer in [1, 32], else 0 (gamma path)
+    float df;
+    float scale;
+};
+
+__device__ float chi2_over_df_gamma(const SamplerArgs& sa, uint32_t i, uint32_t ylo, uint32_t yhi) {
+    // chi2(df)/df with chi2 = 2*Gamma(df/2, 1)  (Marsaglia & Tsang 2000).
+    float shape = 0.5f * sa.df;
+    float boost = 1.0f;
+    uint32_t call = 0x40000000u;
+    if (shape < 1.0f) {
+        const U4 r = philox4x32_10(i, call++, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        boost = powf(u01(r.x), 1.0f / shape);
+        shape += 1.0f;
+    }
+    const float d = shape - (1.0f / 3.0f), c = 1.0f / sqrtf(9.0f * d);
+    float g = d;   // fallback if 64 rejections in a row (probability < 1e-80)
+    for (int it = 0; it < 64; ++it) {
+        const U4 r = philox4x32_10(i, call++, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        float z, unused;
+        box_muller(r.x, r.y, z, unused);
+        float v = 1.0f + c * z;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        const float u = u01(r.z);
+        if (logf(u) < 0.5f * z * z + d - d * v + d * logf(v)) { g = d * v; break; }
+    }
+    return 2.0f * g * boost / sa.df;
+}
+
+// Calls put(d, x_d) for d = 0 .. dx-1 with the proposal sample (yidx, i) around xhat.
+template <typename Put>
+__device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx, uint32_t i,
+                                            const float* xhat, int dx, Put put) {
+    const uint32_t ylo = (uint32_t)yidx, yhi = (uint32_t)(yidx >> 32);
+    float zsum = 0.0f, mult = 0.0f;
+    if (sa.ndf == 0) mult = sa.scale / sqrtf(chi2_over_df_gamma(sa, i, ylo, yhi));
+    const int total = sa.ndf + dx;
+    for (int c = 0; 4 * c < total; ++c) {
+        const U4 r = philox4x32_10(i, (uint32_t)c, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        float n[4];
+        box_muller(r.x, r.y, n[0], n[1]);
+        box_muller(r.z, r.w, n[2], n[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = 4 * c + k;
+            if (g < sa.ndf) {
+                zsum += n[k] * n[k];
+                if (g == sa.ndf - 1) mult = sa.scale / sqrtf(zsum / sa.df);
+            } else if (g < total) {
+                const int d = g - sa.ndf;
+                put(d, xhat[d] + mult * n[k]);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fused IS kernel.
+// ----------------------------------------------------------------------------------------------
+struct IsArgs {
+    MlpArgs g;
+    SamplerArgs sa;
+    const double* y;        // N x dy
+    const float* xhat;      // N x dx
+    const double* xs;       // given samples N x S x dx, or nullptr
+    double* partial;        // n_units x 2 : (max, sum exp(v - max))
+    int64_t N, S, y_index_base;
+    int64_t n_units;
+    int nchunks;            // chunks per query point
+    int chunk;              // samples per chunk (multiple of 64)
+    // score constants (fp64)
+    double c_all;           // -dy*log(sqrt(2pi)*sd) - dx*log(sqrt(2pi)) - dx*ct(df, scale)
+    double inv_2sd2;        // 1 / (2 sd^2)
+    double inv_scale;
+    double inv_df;
+    double half_dfp1;       // (df+1)/2
+};
+
+struct Carve {
+    int x0, act, scr, yb, xh, total;
+};
+
+__host__ __device__ inline Carve carve_for(int hid, int k0, int in_dim, int out_dim) {
+    Carve c;
+    int off = 0;
+    c.x0 = off; off += k0 * 64 * 4;
+    int act_bytes = hid * 64 * 4;
+    const int part_bytes = 4 * out_dim * 64 * 4;
+    if (part_bytes > act_bytes) act_bytes = part_bytes;
+    c.act = off; off += act_bytes;
+    c.scr = off; off += 4 * 64 * 8;
+    c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
+    c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
+    c.total = off;
+    return c;
+}
+
+template <int HID, bool GIVEN>
+__global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MlpArgs& m = a.g;
+    const int dx = m.in_dim, dy = m.out_dim;
+    const Carve cv = carve_for(HID, m.k0, dx, dy);
+    char* x0 = smem + cv.x0;
+    char* act = smem + cv.act;
+    double* scr = (double*)(smem + cv.scr);
+    double* yb = (double*)(smem + cv.yb);
+    float* xh = (float*)(smem + cv.xh);
+    const float* part = (const float*)act;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int s = lane, p = wave;   // scoring role: sample slot s, dimension phase p
+
+    // zero the padded rows of the x0 image once: rows >= dx are never written again
+    for (int i = tid; i < m.k0 * 16; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        const int64_t n = unit / a.nchunks;
+        const int c = (int)(unit - n * a.nchunks);
+        const int64_t s_begin = (int64_t)c * a.chunk;
+        const int64_t s_end = (s_begin + a.chunk < a.S) ? s_begin + a.chunk : a.S;
+        __syncthreads();   // previous unit's readers of yb / xh are done
+        for (int d = tid; d < dy; d += NTHREADS) yb[d] = a.y[n * dy + d];
+        for (int d = tid; d < dx; d += NTHREADS) xh[d] = a.xhat[n * dx + d];
+        __syncthreads();
+
+        double run_m = -INFINITY, run_s = 0.0;   // online log-sum-exp state (wave 0 lanes)
+
+        for (int64_t sb = s_begin; sb < s_end; sb += MS) {
+            const int64_t si = sb + s;           // this thread's sample index
+            // ---- A. proposal samples -> x0 image --------------------------------------------------
+            if (GIVEN) {
+                if (si < s_end) {
+                    const double* src = a.xs + ((size_t)n * a.S + si) * dx;
+                    for (int d = p; d < dx; d += 4)
+                        *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = (float)src[d];
+                } else {
+                    for (int d = p; d < dx; d += 4)
+                        *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = 0.0f;
+                }
+            } else if (wave == 0) {
+                draw_sample(a.sa, (uint64_t)(a.y_index_base + n), (uint32_t)si, xh, dx,
+                            [&](int d, float v) {
+                                *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v;
+                            });
+            }
+            __syncthreads();
+            // ---- B. G forward ---------------------------------------------------------------------
+            mlp_core<HID>(m, x0, act, wave, lane);
+            // ---- C. score: thread (s, p) handles dims d = p, p+4, ... ------------------------------
+            double se = 0.0;
+            for (int d = p; d < dy; d += 4) {
+                const double diff = yb[d] - (double)mlp_out(m, part, d, s);
+                se += diff * diff;
+            }
+            double lw = 0.0;
+            for (int d = p; d < dx; d += 4) {
+                double x;
+                if (GIVEN) x = (si < s_end) ? a.xs[((size_t)n * a.S + si) * dx + d] : 0.0;
+                else x = (double)*(const float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
+                const double u = ((double)xh[d] - x) * a.inv_scale;
+                lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
+            }
+            scr[p * 64 + s] = lw - se * a.inv_2sd2;
+            __syncthreads();
+            // ---- D. online log-sum-exp (wave 0) ----------------------------------------------------
+            if (wave == 0) {
+                const double v = a.c_all + (((scr[s] + scr[64 + s]) + scr[128 + s]) + scr[192 + s]);
+                if (si < s_end && v > -INFINITY && v < INFINITY) {
+                    if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
+                    else run_s += exp(v - run_m);
+                }
+            }
+        }
+        if (wave == 0) {
+            double M = run_m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
+            double t = (run_m > -INFINITY) ? run_s * exp(run_m - M) : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) { a.partial[2 * unit] = M; a.partial[2 * unit + 1] = t; }
+        }
+    }
+}
+
+__global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, double logS,
+                                   int log_flag, double* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double* p = partial + 2 * n * nchunks;
+    double M = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) M = fmax(M, p[2 * c]);
+    double t = 0.0;
+    for (int c = 0; c < nchunks; ++c)
+        if (p[2 * c] > -INFINITY) t += p[2 * c + 1] * exp(p[2 * c] - M);
+    const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
+    out[n] = log_flag ? lp : exp(lp);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Plain MLP forward (predict_x / predict_y): 64 rows per pass.
+// ----------------------------------------------------------------------------------------------
+template <int HID>
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                           float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Carve cv = carve_for(HID, m.k0, m.in_dim, m.out_dim);
+    char* x0 = smem + cv.x0;
+    char* act = smem + cv.act;
+    const float* part = (const float*)act;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    for (int i = tid; i < m.k0 * 16; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t npass = (N + MS - 1) / MS;
+    for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
+        const int64_t row = ps * MS + lane;
+        __syncthreads();
+        for (int d = wave; d < m.in_dim; d += 4)
+            *(float*)(x0 + act_off(d >> 3, lane, (d >> 2) & 1) + 4 * (d & 3)) =
+                (row < N) ? in[row * m.in_dim + d] : 0.0f;
+        __syncthreads();
+        mlp_core<HID>(m, x0, act, wave, lane);
+        if (row < N)
+            for (int d = wave; d < m.out_dim; d += 4) out[row * m.out_dim + d] = mlp_out(m, part, d, lane);
+    }
+}
+
+__global__ void draw_samples_kernel(SamplerArgs sa, const float* xhat, int64_t N, int64_t y_index_base,
+                                    int64_t S, int dx, float* xs) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * S) return;
+    const int64_t n = t / S, i = t - n * S;
+    float* dst = xs + t * dx;
+    draw_sample(sa, (uint64_t)(y_index_base + n), (uint32_t)i, xhat + n * dx, dx,
+                [&](int d, float v) { dst[d] = v; });
+}
+
+// ----------------------------------------------------------------------------------------------
+// Host side
+// ----------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct HostMlp {
+    bool set = false;
+    int n_layers = 0;
+    int hid = 0;
+    std::vector<int> dims;
+    std::vector<void*> dev;   // device allocations to free
+    MlpArgs args;
+    double flops_per_row = 0.0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    HostMlp mlp[2];
+    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double flops_acc = 0.0;
+    uint64_t evals_acc = 0;
+    std::string err;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, RT_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+int ensure(rt_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return RT_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return RT_OK;
+}
+
+// Packs W [K x NF] (row-major, out = in @ W) into per-lane MFMA A-operand order:
+//   packed[((kg*FTT + ft)*64 + lane)*4 + e] = W[8kg + 4h + e][32ft + i],  lane = 32h + i,
+// zero where k >= K or the feature >= NF.  FTT = ceil(NF/32), kg < ceil(K/8).
+void pack_layer(const float* W, int K, int NF, std::vector<float>& out) {
+    const int nkg = (K + 7) / 8, ftt = (NF + 31) / 32;
+    out.assign((size_t)nkg * ftt * 64 * 4, 0.0f);
+    for (int kg = 0; kg < nkg; ++kg)
+        for (int ft = 0; ft < ftt; ++ft)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int h = lane >> 5, i = lane & 31, f = 32 * ft + i;
+                if (f >= NF) continue;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 8 * kg + 4 * h + e;
+                    if (k < K) out[(((size_t)kg * ftt + ft) * 64 + lane) * 4 + e] = W[(size_t)k * NF + f];
+                }
+            }
+}
+
+void free_mlp(HostMlp& m) {
+    for (void* p : m.dev) (void)hipFree(p);
+    m.dev.clear();
+    m.set = false;
+}
+
+template <int HID>
+int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
+    if (given) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((is_fused_kernel<HID, true>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
+    } else {
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((is_fused_kernel<HID, false>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+template <int HID>
+int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* out, int grid, int lds) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_fwd_kernel<HID>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((mlp_fwd_kernel<HID>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, out);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArgs& sa) {
+    if (!(scale > 0.0) || !(df > 0.0) || !isfinite(scale) || !isfinite(df))
+        return fail(ctx, RT_EINVAL, "scale and df must be positive and finite");
+    sa.seed_lo = (uint32_t)seed;
+    sa.seed_hi = (uint32_t)(seed >> 32);
+    sa.df = (float)df;
+    sa.scale = (float)scale;
+    sa.ndf = (df == floor(df) && df <= 32.0) ? (int)df : 0;
+    return RT_OK;
+}
+
+// Enqueues the fused kernel + finalize.  All pointers are device pointers.
+int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
+               int64_t y_index_base, int64_t S, double sd_y, double scale, double df, uint64_t seed,
+               int log_flag, double* out) {
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
+    if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
+    if (!(sd_y > 0.0) || !isfinite(sd_y)) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
+    if (N == 0) return RT_OK;
+    IsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = G.args;
+    int rc = make_sampler(ctx, scale, df, seed, a.sa);
+    if (rc) return rc;
+    const int dx = G.args.in_dim, dy = G.args.out_dim;
+    // work units: (query point, chunk of samples); aim for >= 128 units per CU-resident workgroup
+    const int grid_max = ctx->cu_count;
+    const int64_t passes = (S + MS - 1) / MS;
+    int64_t want = (128ll * grid_max + N - 1) / N;
+    if (want < 1) want = 1;
+    if (want > passes) want = passes;
+    const int64_t ppc = (passes + want - 1) / want;
+    const int64_t nchunks = (passes + ppc - 1) / ppc;
+    a.nchunks = (int)nchunks;
+    a.chunk = (int)(ppc * MS);
+    a.n_units = N * nchunks;
+    a.N = N; a.S = S; a.y_index_base = y_index_base;
+    a.y = y; a.xhat = xhat; a.xs = xs;
+    rc = ensure(ctx, ctx->b_partial, (size_t)a.n_units * 2 * sizeof(double));
+    if (rc) return rc;
+    a.partial = (double*)ctx->b_partial.p;
+    const double PI = 3.14159265358979323846;
+    const double ct = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * PI) - log(scale);
+    a.c_all = -(double)dy * log(sqrt(2.0 * PI) * sd_y) - (double)dx * log(sqrt(2.0 * PI)) - (double)dx * ct;
+    a.inv_2sd2 = 1.0 / (2.0 * sd_y * sd_y);
+    a.inv_scale = 1.0 / scale;
+    a.inv_df = 1.0 / df;
+    a.half_dfp1 = 0.5 * (df + 1.0);
+
+    const Carve cv = carve_for(G.hid, G.args.k0, dx, dy);
+    const int grid = (int)((a.n_units < grid_max) ? a.n_units : grid_max);
+    if (ctx->events_used == ctx->events.size()) {
+        hipEvent_t e0, e1;
+        HIPCHK(ctx, hipEventCreate(&e0));
+        HIPCHK(ctx, hipEventCreate(&e1));
+        ctx->events.emplace_back(e0, e1);
+    }
+    auto& ev = ctx->events[ctx->events_used];
+    HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
+    switch (G.hid) {
+        case 128: rc = launch_is<128>(ctx, a, xs != nullptr, grid, cv.total); break;
+        case 256: rc = launch_is<256>(ctx, a, xs != nullptr, grid, cv.total); break;
+        case 512: rc = launch_is<512>(ctx, a, xs != nullptr, grid, cv.total); break;
+        default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
+    }
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
+    ctx->events_used++;
+    ctx->flops_acc += (double)N * (double)S * G.flops_per_row;
+    ctx->evals_acc += (uint64_t)N * (uint64_t)S;
+    const int fb = 256;
+    hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + fb - 1) / fb)), dim3(fb), 0, ctx->stream,
+                       (const double*)a.partial, N, a.nchunks, log((double)S), log_flag, out);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) {
+    if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
+    HostMlp& M = ctx->mlp[which];
+    if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N == 0) return RT_OK;
+    const Carve cv = carve_for(M.hid, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const int64_t npass = (N + MS - 1) / MS;
+    const int64_t gmax = (int64_t)ctx->cu_count * 2;
+    const int grid = (int)(npass < gmax ? npass : gmax);
+    switch (M.hid) {
+        case 128: return launch_fwd<128>(ctx, M.args, in, N, out, grid, cv.total);
+        case 256: return launch_fwd<256>(ctx, M.args, in, N, out, grid, cv.total);
+        case 512: return launch_fwd<512>(ctx, M.args, in, N, out, grid, cv.total);
+        default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_ctx_create(int device, rt_ctx** out) {
+    if (!out) return fail(nullptr, RT_EINVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(nullptr, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(nullptr, RT_EINVAL, "no such HIP device");
+    HIPCHK(nullptr, hipSetDevice(device));
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ENOMEM, "out of host memory");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
+    ctx->cu_count = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_mlp(ctx->mlp[0]);
+    free_mlp(ctx->mlp[1]);
+    DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout};
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const float* const* W,
+               const float* const* b, float lrelu_alpha) {
+    if (!ctx) return RT_EINVAL;
+    if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
+    if (!dims || !W || !b) return fail(ctx, RT_EINVAL, "NULL argument");
+    if (n_layers < 2 || n_layers > RT_MAX_LAYERS) return fail(ctx, RT_EINVAL, "n_layers must be in [2, RT_MAX_LAYERS]");
+    if (!(lrelu_alpha >= 0.0f && lrelu_alpha <= 1.0f)) return fail(ctx, RT_EINVAL, "lrelu_alpha must be in [0, 1]");
+    for (int l = 0; l <= n_layers; ++l) if (dims[l] < 1) return fail(ctx, RT_EINVAL, "dims must be >= 1");
+    for (int l = 0; l < n_layers; ++l) if (!W[l] || !b[l]) return fail(ctx, RT_EINVAL, "NULL weight or bias");
+    const int hid = dims[1];
+    for (int l = 1; l < n_layers; ++l)
+        if (dims[l] != hid) return fail(ctx, RT_EUNSUPPORTED, "all hidden layers must have the same width");
+    if (hid != 128 && hid != 256 && hid != 512)
+        return fail(ctx, RT_EUNSUPPORTED, "hidden width must be 128, 256 or 512");
+    if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 64");
+    if (dims[n_layers] > MAX_OUT) return fail(ctx, RT_EUNSUPPORTED, "output dim > 128");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HostMlp& M = ctx->mlp[which];
+    free_mlp(M);
+    M.n_layers = n_layers;
+    M.hid = hid;
+    M.dims.assign(dims, dims + n_layers + 1);
+    memset(&M.args, 0, sizeof(M.args));
+    M.args.n_layers = n_layers;
+    M.args.in_dim = dims[0];
+    M.args.out_dim = dims[n_layers];
+    M.args.k0 = ((dims[0] + 7) / 8) * 8;
+    M.args.nt_out = (dims[n_layers] + 31) / 32;
+    M.args.alpha = lrelu_alpha;
+    M.flops_per_row = 0.0;
+    std::vector<float> packed, bias;
+    for (int l = 0; l < n_layers; ++l) {
+        const int K = dims[l], NF = dims[l + 1];
+        M.flops_per_row += 2.0 * (double)K * (double)NF;
+        pack_layer(W[l], K, NF, packed);
+        // one extra zero k-group of padding keeps any speculative prefetch in bounds
+        const size_t pad = (size_t)((NF + 31) / 32) * 64 * 4;
+        packed.resize(packed.size() + pad, 0.0f);
+        void* dw = nullptr;
+        HIPCHK(ctx, hipMalloc(&dw, packed.size() * sizeof(float)));
+        M.dev.push_back(dw);
+        HIPCHK(ctx, hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        bias.assign((size_t)((NF + 31) / 32) * 32, 0.0f);
+        memcpy(bias.data(), b[l], sizeof(float) * NF);
+        void* db = nullptr;
+        HIPCHK(ctx, hipMalloc(&db, bias.size() * sizeof(float)));
+        M.dev.push_back(db);
+        HIPCHK(ctx, hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+        M.args.wp[l] = (const float*)dw;
+        M.args.bp[l] = (const float*)db;
+    }
+    M.set = true;
+    return RT_OK;
+}
+
+int rt_mlp_forward_dev(rt_ctx* ctx, int which, const float* in_dev, int64_t N, float* out_dev) {
+    if (!ctx) return RT_EINVAL;
+    if (N > 0 && (!in_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return fwd_enqueue(ctx, which, in_dev, N, out_dev);
+}
+
+int rt_mlp_forward(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) {
+    if (!ctx) return RT_EINVAL;
+    if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
+    HostMlp& M = ctx->mlp[which];
+    if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N == 0) return RT_OK;
+    if (!in || !out) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t ib = (size_t)N * M.args.in_dim * sizeof(float), ob = (size_t)N * M.args.out_dim * sizeof(float);
+    int rc = ensure(ctx, ctx->b_in, ib); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_fout, ob); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_in.p, in, ib, hipMemcpyHostToDevice, ctx->stream));
+    rc = fwd_enqueue(ctx, which, (const float*)ctx->b_in.p, N, (float*)ctx->b_fout.p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_fout.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat) {
+    return rt_mlp_forward(ctx, RT_MLP_H, y, N, xhat);
+}
+
+static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
+                   int64_t y_index_base, int64_t S, double sd_y, double scale, double df, uint64_t seed,
+                   int log_flag, double* out, bool given) {
+    if (!ctx) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N == 0) return RT_OK;
+    if (!y || !xhat || !out || (given && !xs)) return fail(ctx, RT_EINVAL, "NULL argument");
+    if (S <= 0) return fail(ctx, RT_EINVAL, "S must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int dx = G.args.in_dim, dy = G.args.out_dim;
+    const size_t yb = (size_t)N * dy * sizeof(double), xb = (size_t)N * dx * sizeof(float);
+    int rc = ensure(ctx, ctx->b_y, yb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_xhat, xb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_out, (size_t)N * sizeof(double)); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_y.p, y, yb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_xhat.p, xhat, xb, hipMemcpyHostToDevice, ctx->stream));
+    const double* xs_dev = nullptr;
+    if (given) {
+        const size_t sbytes = (size_t)N * (size_t)S * dx * sizeof(double);
+        rc = ensure(ctx, ctx->b_xs, sbytes); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->b_xs.p, xs, sbytes, hipMemcpyHostToDevice, ctx->stream));
+        xs_dev = (const double*)ctx->b_xs.p;
+    }
+    rc = is_enqueue(ctx, (const double*)ctx->b_y.p, (const float*)ctx->b_xhat.p, xs_dev, N, y_index_base,
+                    S, sd_y, scale, df, seed, log_flag, (double*)ctx->b_out.p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_is_estimate(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                   int64_t S, double sd_y, double scale, double df, uint64_t seed, int log_flag,
+                   double* out) {
+    return is_host(ctx, y, xhat, nullptr, N, y_index_base, S, sd_y, scale, df, seed, log_flag, out, false);
+}
+
+int rt_is_estimate_given_samples(rt_ctx* ctx, const double* y, const float* xhat, const double* x_samples,
+                                 int64_t N, int64_t S, double sd_y, double scale, double df, int log_flag,
+                                 double* out) {
+    return is_host(ctx, y, xhat, x_samples, N, 0, S, sd_y, scale, df, 0, log_flag, out, true);
+}
+
+int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
+                       int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
+                       uint64_t seed, int log_flag, double* out_dev) {
+    if (!ctx) return RT_EINVAL;
+    if (N > 0 && (!y_dev || !xhat_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, sd_y, scale, df, seed, log_flag, out_dev);
+}
+
+int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,
+                    double scale, double df, uint64_t seed, float* x_samples) {
+    if (!ctx) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set (it defines dx)");
+    if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
+    if (N == 0) return RT_OK;
+    if (!xhat || !x_samples) return fail(ctx, RT_EINVAL, "NULL argument");
+    SamplerArgs sa;
+    int rc = make_sampler(ctx, scale, df, seed, sa);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int dx = G.args.in_dim;
+    const size_t xb = (size_t)N * dx * sizeof(float), sb = (size_t)N * (size_t)S * dx * sizeof(float);
+    rc = ensure(ctx, ctx->b_xhat, xb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_xs, sb); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_xhat.p, xhat, xb, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t total = N * S;
+    hipLaunchKernelGGL(draw_samples_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       sa, (const float*)ctx->b_xhat.p, N, y_index_base, S, dx, (float*)ctx->b_xs.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(x_samples, ctx->b_xs.p, sb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
+    if (!ctx || !out) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        float t = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->events[i].first, ctx->events[i].second));
+        ms += t;
+    }
+    out->kernel_ms = ms;
+    out->flops = ctx->flops_acc;
+    out->launches = ctx->events_used;
+    out->sample_evals = ctx->evals_acc;
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_ctx* ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->events_used = 0;
+    ctx->flops_acc = 0.0;
+    ctx->evals_acc = 0;
+    return RT_OK;
+}
+
+int rt_device_cu_count(rt_ctx* ctx, int* out) {
+    if (!ctx || !out) return RT_EINVAL;
+    *out = ctx->cu_count;
+    return RT_OK;
+}
+
+}  // extern "C"
