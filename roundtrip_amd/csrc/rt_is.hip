@@ -35,7 +35,8 @@ namespace {
 
 constexpr int MS = 64;          // samples per workgroup pass
 constexpr int NTHREADS = 256;   // 4 waves, one per SIMD
-constexpr int MAX_IN = 64;      // max input dim of a fused MLP (dx for G)
+constexpr int MAX_IN = 128;     // max input dim of a fused MLP (also bounded by the LDS budget)
+constexpr int LDS_MAX = 160 * 1024;
 constexpr int MAX_OUT = 128;    // max output dim of a fused MLP (dy for G)
 
 struct MlpArgs {
@@ -755,8 +756,10 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
         if (dims[l] != hid) return fail(ctx, RT_EUNSUPPORTED, "all hidden layers must have the same width");
     if (hid != 128 && hid != 256 && hid != 512)
         return fail(ctx, RT_EUNSUPPORTED, "hidden width must be 128, 256 or 512");
-    if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 64");
+    if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 128");
     if (dims[n_layers] > MAX_OUT) return fail(ctx, RT_EUNSUPPORTED, "output dim > 128");
+    if (carve_for(hid, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
+        return fail(ctx, RT_EUNSUPPORTED, "input dim too large for this hidden width (LDS budget of 160 KiB)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HostMlp& M = ctx->mlp[which];

@@ -1,0 +1,240 @@
+"""Drop-in model objects for the importance-sampling density estimator.
+
+`Roundtrip` mirrors the v2 class (/root/reference/src/pyroundtrip/roundtrip.py:9-58, 229-310): same
+constructor arguments, same `params` keys, same attributes on this path (g_net, e_net, params,
+save_dir, checkpoint_path) and the same `estimate_px_with_IS` signature.  `RoundtripModel` mirrors the
+v1 class (/root/reference/main_density_est.py:29-44, 222-249, 266-348, 397-411).  Both spellings of the
+estimator exist on both classes (BASELINE.json's north_star mixes them).
+
+Everything numerical runs in librt_is.so on an MI355X; there is no CPU path in this package.
+"""
+import datetime
+import os
+
+import numpy as np
+
+from . import _lib, dist
+from .nets import BaseFullyConnectedNet, DenseNet
+
+
+def _default_device():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class _IsModelBase(object):
+    """Shared machinery: the device engine, lazy weight upload, the estimator itself."""
+
+    #: seed of the counter-based proposal sampler.  The reference reseeds numpy's global RNG with 0 at
+    #: every call (main_density_est.py:267), i.e. "same call => same answer"; a fixed default keeps that.
+    is_seed = 0
+    #: shard query points over torch.distributed ranks when a process group is initialised
+    shard = True
+
+    def _init_engine_state(self, device):
+        self._device = device
+        self._engine = None
+        self._uploaded = {}
+
+    # ---- engine ---------------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            dev = self._device if self._device is not None else _default_device()
+            self._engine = _lib.Engine(dev)   # raises if librt_is.so or the GPU is missing
+        return self._engine
+
+    def _nets(self):
+        raise NotImplementedError
+
+    def _sync_weights(self):
+        eng = self.engine
+        for which, net in self._nets():
+            if self._uploaded.get(which) != (id(net), net.version):
+                eng.set_mlp(which, net.weights, net.biases, net.alpha)
+                self._uploaded[which] = (id(net), net.version)
+
+    def _bind(self):
+        for which, net in self._nets():
+            net._forward = (lambda x, _w=which: self._forward(_w, x))
+
+    def _forward(self, which, x):
+        self._sync_weights()
+        return self.engine.mlp_forward(which, x)
+
+    # ---- the estimator ----------------------------------------------------------------------------
+    def _estimate_is(self, points, sd, scale, sample_size, df, log):
+        g_net = self._nets()[0][1]
+        e_net = self._nets()[1][1]
+        points = np.asarray(points)
+        assert points.ndim == 2 and points.shape[-1] == g_net.output_dim
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        self._sync_weights()
+        eng = self.engine
+
+        def block(pts, base):
+            # proposal centres H(y): predict_x (main_density_est.py:320) / self.e_net(x_points) (roundtrip.py:283)
+            centres = eng.mlp_forward(_lib.RT_MLP_H, pts.astype(np.float32))
+            return eng.is_estimate(pts, centres, sample_size, sd, scale, df=df, seed=self.is_seed, log=log,
+                                   y_index_base=base)
+
+        if self.shard and dist.world()[1] > 1:
+            return dist.sharded_map(points, block)
+        if points.shape[0] == 0:
+            return np.zeros(0, dtype=np.float64)
+        return block(points, 0)
+
+
+class Roundtrip(_IsModelBase):
+    """Roundtrip model for density estimation — the importance-sampling path (v2 API)."""
+
+    def __init__(self, params, timestamp=None, random_seed=None, device=None):
+        super(Roundtrip, self).__init__()
+        self.params = params
+        self.timestamp = timestamp
+        rng = np.random.RandomState(random_seed)
+        self.g_net = BaseFullyConnectedNet(input_dim=params['z_dim'], output_dim=params['x_dim'],
+                                           model_name='g_net', nb_units=params['g_units'], rng=rng)
+        self.e_net = BaseFullyConnectedNet(input_dim=params['x_dim'], output_dim=params['z_dim'],
+                                           model_name='e_net', nb_units=params['e_units'], rng=rng)
+        # dz_net / dx_net / optimizers (roundtrip.py:22-29) belong to training, which is out of scope.
+        if self.timestamp is None:
+            now = datetime.datetime.now().astimezone()
+            self.timestamp = now.strftime('%Y%m%d_%H%M%S')
+        out_dir = params.get('output_dir', '.')
+        dataset = params.get('dataset', 'data')
+        self.checkpoint_path = "{}/checkpoints/{}/{}".format(out_dir, dataset, self.timestamp)
+        if params.get('save_model', False) and not os.path.exists(self.checkpoint_path):
+            os.makedirs(self.checkpoint_path)
+        self.save_dir = "{}/results/{}/{}".format(out_dir, dataset, self.timestamp)
+        if not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir)
+        self._init_engine_state(device)
+        self._bind()
+        # roundtrip.py:56-58: restore the latest checkpoint under checkpoint_path if there is one
+        from . import checkpoint
+        latest = checkpoint.latest_checkpoint(self.checkpoint_path)
+        if latest:
+            self.restore(latest)
+            print('Latest checkpoint restored!!')
+
+    def get_config(self):
+        return {"params": self.params}
+
+    def _nets(self):
+        return ((_lib.RT_MLP_G, self.g_net), (_lib.RT_MLP_H, self.e_net))
+
+    def restore(self, prefix):
+        """Loads g_net / e_net from a tf.train.Checkpoint written by the reference (roundtrip.py:48-57)."""
+        from . import checkpoint
+        checkpoint.load_v2(prefix, self.g_net, self.e_net)
+
+    def estimate_px_with_IS(self, x_points, sd_x=0.5, scale=0.5, sample_size=40000, bs=1024, df=1, log=True):
+        """p(x) (or log p(x)) of every row of x_points by importance sampling (roundtrip.py:229-310).
+        `bs` only batches work in the reference and has no effect here."""
+        x_points = np.asarray(x_points)
+        assert x_points.shape[-1] == self.params['x_dim']
+        return self._estimate_is(x_points, sd_x, scale, sample_size, df, log)
+
+    def estimate_py_with_IS(self, y_points, epoch=0, sd_y=0.5, scale=0.5, sample_size=40000, bs=1024, log=True,
+                            save=True, df=1):
+        """v1 spelling (main_density_est.py:266): y is the data point.  `save` writes
+        '<save_dir>/py_est_at_epoch<epoch>.npy' like the reference (:346-347)."""
+        py_est = self.estimate_px_with_IS(y_points, sd_x=sd_y, scale=scale, sample_size=sample_size, bs=bs,
+                                          df=df, log=log)
+        if save:
+            np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
+        return py_est
+
+    def save(self, fname, data):
+        # roundtrip.py:371-378
+        if fname[-3:] == 'npy':
+            np.save(fname, data)
+        elif fname[-3:] in ('txt', 'csv'):
+            np.savetxt(fname, data, fmt='%.6f')
+        else:
+            raise ValueError('Wrong saving format, please specify either .npy, .txt, or .csv')
+
+
+class RoundtripModel(_IsModelBase):
+    """v1 API (main_density_est.py:29-44).  g_net / h_net are roundtrip_amd.nets.Generator objects
+    (model.Generator's constructor, model.py:54); dx_net / dy_net, the samplers and the pool are training
+    parts and may be None."""
+
+    def __init__(self, g_net, h_net, dx_net=None, dy_net=None, x_sampler=None, y_sampler=None, data='data',
+                 pool=None, batch_size=64, alpha=10.0, beta=10.0, df=1, is_train=False, device=None):
+        if not isinstance(g_net, DenseNet) or not isinstance(h_net, DenseNet):
+            raise TypeError("g_net and h_net must be roundtrip_amd.nets.Generator / DenseNet objects")
+        if g_net.input_dim != h_net.output_dim or g_net.output_dim != h_net.input_dim:
+            raise ValueError("g_net maps %d->%d but h_net maps %d->%d"
+                             % (g_net.input_dim, g_net.output_dim, h_net.input_dim, h_net.output_dim))
+        self.data = data
+        self.g_net = g_net
+        self.h_net = h_net
+        self.dx_net = dx_net
+        self.dy_net = dy_net
+        self.x_sampler = x_sampler
+        self.y_sampler = y_sampler
+        self.batch_size = batch_size
+        self.alpha = alpha
+        self.beta = beta
+        self.df = df
+        self.pool = pool
+        self.x_dim = g_net.input_dim     # reference: self.dx_net.input_dim (:43)
+        self.y_dim = g_net.output_dim    # reference: self.dy_net.input_dim (:44)
+        now = datetime.datetime.now().astimezone()
+        self.timestamp = now.strftime('%Y%m%d_%H%M%S')
+        self.save_dir = 'data/density_est_{}_{}_x_dim={}_y_dim={}_alpha={}_beta={}'.format(
+            self.timestamp, self.data, self.x_dim, self.y_dim, self.alpha, self.beta)
+        if not os.path.exists(self.save_dir) and is_train:
+            os.makedirs(self.save_dir)
+        self._init_engine_state(device)
+        self._bind()
+
+    def _nets(self):
+        return ((_lib.RT_MLP_G, self.g_net), (_lib.RT_MLP_H, self.h_net))
+
+    def predict_y(self, x, bs=256):
+        # main_density_est.py:222-234: float64 container holding float32 values
+        x = np.asarray(x)
+        assert x.shape[-1] == self.x_dim
+        return self._forward(_lib.RT_MLP_G, np.ascontiguousarray(x, dtype=np.float32)).astype(np.float64)
+
+    def predict_x(self, y, bs=256):
+        # main_density_est.py:237-249
+        y = np.asarray(y)
+        assert y.shape[-1] == self.y_dim
+        return self._forward(_lib.RT_MLP_H, np.ascontiguousarray(y, dtype=np.float32)).astype(np.float64)
+
+    def estimate_py_with_IS(self, y_points, epoch, sd_y=0.5, scale=0.5, sample_size=40000, bs=1024, log=True,
+                            save=True):
+        """main_density_est.py:266-348; df comes from self.df (:41)."""
+        y_points = np.asarray(y_points)
+        assert y_points.shape[-1] == self.y_dim
+        py_est = self._estimate_is(y_points, sd_y, scale, sample_size, self.df, log)
+        if save:
+            if not os.path.exists(self.save_dir):
+                os.makedirs(self.save_dir)
+            np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
+        return py_est
+
+    def estimate_px_with_IS(self, x_points, sd_x=0.5, scale=0.5, sample_size=40000, bs=1024, df=1, log=True):
+        """v2 spelling on the v1 object (x is the data point there)."""
+        x_points = np.asarray(x_points)
+        assert x_points.shape[-1] == self.y_dim
+        return self._estimate_is(x_points, sd_x, scale, sample_size, df, log)
+
+    def load(self, pre_trained=False, timestamp='', epoch=999):
+        """main_density_est.py:397-411: restores G / H from a tf.train.Saver checkpoint."""
+        from . import checkpoint
+        if pre_trained:
+            print('Loading Pre-trained Model...')
+            checkpoint_dir = 'pre_trained_models/{}'.format(self.data)
+            checkpoint.load_v1(os.path.join(checkpoint_dir, 'model.ckpt-best'), self.g_net, self.h_net)
+            print('Restored pre-trained model.')
+        elif timestamp == '':
+            print('Best Timestamp not provided.')
+        else:
+            checkpoint_dir = 'checkpoint/density_est_{}_{}_x_dim={}_y_dim={}_alpha={}_beta={}'.format(
+                timestamp, self.data, self.x_dim, self.y_dim, self.alpha, self.beta)
+            checkpoint.load_v1(os.path.join(checkpoint_dir, 'model.ckpt-%d' % epoch), self.g_net, self.h_net)
+            print('Restored model weights.')

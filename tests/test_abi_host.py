@@ -1,0 +1,298 @@
+"""CPU tests (no GPU, no compute calls): the C-ABI library loads and exports every symbol include/rt_is.h
+declares; the host-side mirror of the reference interface (nets, model objects, checkpoint reader,
+sharding) behaves like the reference's."""
+import os
+import re
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from roundtrip_amd import _lib, checkpoint as ck, dist as rdist
+from roundtrip_amd import BaseFullyConnectedNet, Generator, Roundtrip, RoundtripModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ----------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_is.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_no_silent_cpu_fallback_without_gpu():
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.RtError):
+        _lib.Engine(0)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under roundtrip_amd/ may import, link or execute it."""
+    pkg = os.path.join(ROOT, "roundtrip_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, fn)
+
+
+# ---- nets / model objects -------------------------------------------------------------------------------
+def test_generator_shapes_follow_reference_constructors():
+    g = Generator(2, 3, "g_net", nb_layers=10, nb_units=512, rng=np.random.RandomState(0))   # model.py:54
+    assert g.dims == [2] + [512] * 10 + [3]
+    assert [w.shape for w in g.weights][:2] == [(2, 512), (512, 512)] and g.weights[-1].shape == (512, 3)
+    assert all(np.all(b == 0) for b in g.biases)                      # zero-initialised biases
+    lim = np.sqrt(6.0 / (512 + 512))
+    assert np.abs(g.weights[3]).max() <= lim                           # Glorot uniform
+    e = BaseFullyConnectedNet(3, 2, "e_net", nb_units=[256] * 10, rng=np.random.RandomState(0))  # v2 model.py:7
+    assert e.dims == [3] + [256] * 10 + [2]
+    with pytest.raises(NotImplementedError):
+        BaseFullyConnectedNet(3, 2, "e_net", nb_units=[8], batchnorm=True)
+    with pytest.raises(ValueError):
+        BaseFullyConnectedNet(3, 2, "e_net", nb_units=[])
+    with pytest.raises(ValueError):
+        g.set_weights(g.weights[:-1], g.biases[:-1])
+    bad = [w.copy() for w in g.weights]
+    bad[2] = bad[2][:, :100]
+    with pytest.raises(ValueError):
+        g.set_weights(bad, g.biases)
+    v = g.version
+    g.set_weights(g.weights, g.biases)
+    assert g.version == v + 1
+
+
+def _params(tmp_path, **kw):
+    p = dict(dataset="indep_gmm", output_dir=str(tmp_path), x_dim=2, z_dim=2, lr=2e-4, alpha=10, beta=1, gamma=0,
+             g_d_freq=1, g_units=[128] * 3, e_units=[128] * 3, dz_units=[128, 128], dx_units=[256] * 4,
+             save_model=False, sd_x=0.05, scale=0.5, sample_size=20000)
+    p.update(kw)
+    return p
+
+
+def test_roundtrip_v2_constructor_mirrors_reference(tmp_path):
+    m = Roundtrip(_params(tmp_path), timestamp="t0", random_seed=123)          # roundtrip.py:12
+    assert m.g_net.input_dim == 2 and m.g_net.output_dim == 2 and m.e_net.nb_units == [128] * 3
+    assert m.checkpoint_path == "%s/checkpoints/indep_gmm/t0" % tmp_path        # roundtrip.py:36
+    assert m.save_dir == "%s/results/indep_gmm/t0" % tmp_path and os.path.isdir(m.save_dir)   # :42-46
+    assert not os.path.exists(m.checkpoint_path)                               # save_model False
+    assert m.get_config() == {"params": m.params}
+    m2 = Roundtrip(_params(tmp_path), timestamp="t0", random_seed=123)
+    assert all(np.array_equal(a, b) for a, b in zip(m.g_net.get_weights(), m2.g_net.get_weights()))
+    m3 = Roundtrip(_params(tmp_path, save_model=True), timestamp="t1")
+    assert os.path.isdir(m3.checkpoint_path)
+    # signatures kept verbatim
+    import inspect
+    sig = inspect.signature(Roundtrip.estimate_px_with_IS)
+    assert list(sig.parameters)[1:] == ["x_points", "sd_x", "scale", "sample_size", "bs", "df", "log"]
+    assert [sig.parameters[k].default for k in list(sig.parameters)[2:]] == [0.5, 0.5, 40000, 1024, 1, True]
+    sig = inspect.signature(RoundtripModel.estimate_py_with_IS)
+    assert list(sig.parameters)[1:] == ["y_points", "epoch", "sd_y", "scale", "sample_size", "bs", "log", "save"]
+    assert [sig.parameters[k].default for k in list(sig.parameters)[3:]] == [0.5, 0.5, 40000, 1024, True, True]
+    with pytest.raises(AssertionError):            # reference: assert x.shape[-1] == self.x_dim
+        m.estimate_px_with_IS(np.zeros((4, 3)))
+
+
+def test_roundtrip_v2_restores_latest_checkpoint(tmp_path, capsys):
+    src = Roundtrip(_params(tmp_path), timestamp="src", random_seed=1)
+    ckdir = "%s/checkpoints/indep_gmm/run" % tmp_path
+    os.makedirs(ckdir)
+    ck.save_v2(os.path.join(ckdir, "ckpt-3"), src.g_net, src.e_net)
+    ck.write_checkpoint_state(ckdir, "ckpt-3")
+    m = Roundtrip(_params(tmp_path), timestamp="run", random_seed=2)          # roundtrip.py:56-58
+    assert "Latest checkpoint restored!!" in capsys.readouterr().out
+    assert all(np.array_equal(a, b) for a, b in zip(src.g_net.get_weights(), m.g_net.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(src.e_net.get_weights(), m.e_net.get_weights()))
+
+
+def test_roundtrip_model_v1(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = Generator(3, 6, "g_net", 3, 128, rng=np.random.RandomState(0))
+    h = Generator(6, 3, "h_net", 3, 128, rng=np.random.RandomState(1))
+    m = RoundtripModel(g, h, None, None, None, None, "arem", None, 64, 10.0, 10.0, 1, False)   # :30
+    assert (m.x_dim, m.y_dim, m.df) == (3, 6, 1)
+    assert m.save_dir.startswith("data/density_est_") and m.save_dir.endswith("_arem_x_dim=3_y_dim=6_alpha=10.0_beta=10.0")
+    with pytest.raises(ValueError):
+        RoundtripModel(g, Generator(5, 3, "h_net", 3, 128))
+    with pytest.raises(AssertionError):
+        m.estimate_py_with_IS(np.zeros((4, 5)), 0)
+    # v1 load(): checkpoint/density_est_<ts>_<data>_x_dim=..  (main_density_est.py:409-410)
+    d = "checkpoint/density_est_TS_arem_x_dim=3_y_dim=6_alpha=10.0_beta=10.0"
+    g2 = Generator(3, 6, "g_net", 3, 128, rng=np.random.RandomState(5))
+    h2 = Generator(6, 3, "h_net", 3, 128, rng=np.random.RandomState(6))
+    ck.save_v1(os.path.join(d, "model.ckpt-7"), g2, h2)
+    m.load(timestamp="TS", epoch=7)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(h.get_weights(), h2.get_weights()))
+
+
+# ---- checkpoint format -----------------------------------------------------------------------------------
+def test_crc32c_known_answers():
+    assert ck.crc32c(b"123456789") == 0xE3069283            # the standard CRC-32C check value
+    assert ck.crc32c(b"\x00" * 32) == 0x8A9136AA            # RFC 3720 B.4
+    assert ck.mask_crc(0) == 0xa282ead8
+
+
+def test_varint_and_proto_roundtrip():
+    for v in (0, 1, 127, 128, 300, 2 ** 32, 2 ** 63 - 1):
+        enc = ck._put_varint(v)
+        assert ck._get_varint(enc, 0) == (v, len(enc))
+    e = ck.parse_bundle_entry(ck._encode_bundle_entry(ck.DT_FLOAT, (512, 2), 4096, 4096, 0xdeadbeef))
+    assert e["dtype"] == 1 and e["shape"] == [512, 2] and e["offset"] == 4096 and e["size"] == 4096
+    assert e["crc32c"] == 0xdeadbeef and not e["sliced"]
+
+
+def test_sstable_multi_block_prefix_compression(tmp_path):
+    items = [(("scope/var_%04d/weights" % i).encode(), os.urandom(1 + i % 7)) for i in range(500)]
+    items.append((b"", b"hdr"))
+    path = str(tmp_path / "t.index")
+    ck.write_table(path, items, block_entries=37)
+    assert ck.read_table(path) == sorted(items)
+    raw = bytearray(open(path, "rb").read())
+    raw[10] ^= 0xFF
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        ck.read_table(path)
+    with pytest.raises(ValueError):
+        open(path, "wb").write(b"\x00" * 100)
+        ck.read_table(path)
+
+
+def test_snappy_block_decoding():
+    # literal "abcd" + copy(offset 4, len 8) + literal "xyz"  -> "abcdabcdabcdxyz"
+    raw = bytes([15]) + bytes([3 << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + bytes([2 << 2]) + b"xyz"
+    assert ck._snappy_uncompress(raw) == b"abcdabcdabcdxyz"
+    with pytest.raises(ValueError):
+        ck._snappy_uncompress(bytes([4]) + bytes([((8 - 4) << 2) | 1, 9]))
+
+
+def test_bundle_roundtrip_and_names(tmp_path):
+    g = Generator(2, 2, "g_net", 10, 64, rng=np.random.RandomState(0))
+    h = Generator(2, 2, "h_net", 10, 32, rng=np.random.RandomState(1))
+    prefix = str(tmp_path / "model.ckpt-12")
+    ck.save_v1(prefix, g, h)
+    r = ck.BundleReader(prefix)
+    # variable names of tcl.fully_connected under tf.variable_scope(name)
+    assert "g_net/fully_connected/weights" in r.entries and "h_net/fully_connected_10/biases" in r.entries
+    assert len(r.keys()) == 2 * 2 * 11
+    assert r.shape("g_net/fully_connected_10/weights") == (64, 2)
+    w = r.get_tensor("g_net/fully_connected_3/weights", verify=True)
+    assert np.array_equal(w, g.weights[3])
+    # Adam slots and other variables in the file are ignored by the loader
+    extra = {"g_net/fully_connected/weights/Adam": np.zeros((2, 64), np.float32), "beta1_power": np.float32(0.5)}
+    t = ck._net_tensors(g, ck.v1_names("g_net", 11))
+    t.update(ck._net_tensors(h, ck.v1_names("h_net", 11)))
+    t.update(extra)
+    ck.write_bundle(prefix, t)
+    g2 = Generator(2, 2, "g_net", 10, 64)
+    h2 = Generator(2, 2, "h_net", 10, 32)
+    ck.load_v1(prefix, g2, h2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    with pytest.raises(KeyError):
+        ck.load_v1(prefix, Generator(2, 2, "g_net", 11, 64), h2)       # one layer too many
+    with pytest.raises(FileNotFoundError):
+        ck.BundleReader(str(tmp_path / "nope"))
+    # data checksum is checked on request
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[5] ^= 1
+    open(data, "wb").write(bytes(raw))
+    r = ck.BundleReader(prefix)
+    bad = 0
+    for k in r.keys():
+        try:
+            r.get_tensor(k, verify=True)
+        except ValueError:
+            bad += 1
+    assert bad == 1
+
+
+def test_v2_object_graph_keys_and_tolerant_lookup(tmp_path):
+    g = BaseFullyConnectedNet(2, 2, "g_net", [16, 16], rng=np.random.RandomState(0))
+    e = BaseFullyConnectedNet(2, 2, "e_net", [8, 8], rng=np.random.RandomState(1))
+    prefix = str(tmp_path / "ckpt-1")
+    ck.save_v2(prefix, g, e)
+    assert "g_net/all_layers/0/0/kernel/.ATTRIBUTES/VARIABLE_VALUE" in ck.BundleReader(prefix).entries
+    # a different object-graph spelling with the same shapes is still found (the v2 path is unverified)
+    sfx = "/.ATTRIBUTES/VARIABLE_VALUE"
+    t = {}
+    for attr, net in (("g_net", g), ("e_net", e)):
+        for i, (w, b) in enumerate(zip(net.weights, net.biases)):
+            t["%s/layer_with_weights-%d/kernel%s" % (attr, i, sfx)] = w
+            t["%s/layer_with_weights-%d/bias%s" % (attr, i, sfx)] = b
+            t["%s/layer_with_weights-%d/kernel/.OPTIMIZER_SLOT/g_e_optimizer/m%s" % (attr, i, sfx)] = w * 0
+    ck.write_bundle(prefix, t)
+    g2 = BaseFullyConnectedNet(2, 2, "g_net", [16, 16])
+    e2 = BaseFullyConnectedNet(2, 2, "e_net", [8, 8])
+    ck.load_v2(prefix, g2, e2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(e.get_weights(), e2.get_weights()))
+    with pytest.raises(KeyError):
+        ck.load_v2(prefix, BaseFullyConnectedNet(2, 2, "g_net", [16, 16, 16]), e2)
+
+
+def test_latest_checkpoint(tmp_path):
+    assert ck.latest_checkpoint(str(tmp_path)) is None
+    ck.write_checkpoint_state(str(tmp_path), "ckpt-9")
+    assert ck.latest_checkpoint(str(tmp_path)) == os.path.join(str(tmp_path), "ckpt-9")
+
+
+# ---- sharding ---------------------------------------------------------------------------------------------
+def test_shard_bounds_cover_exactly():
+    for n in (0, 1, 7, 8, 9, 10000, 1000003):
+        for ws in (1, 2, 3, 8):
+            blocks = [rdist.shard_bounds(n, ws, r) for r in range(ws)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            per = -(-n // ws) if n else 0
+            assert all(hi - lo <= per for lo, hi in blocks)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [11, 2])
+def test_sharded_map_world_size_2_gloo(tmp_path, n):
+    """N > 1 path on CPU: two gloo ranks each evaluate their contiguous block with the global index base
+    and the all-gather assembles exactly the unsharded answer."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import torch.distributed as dist
+        from roundtrip_amd import dist as rdist
+        dist.init_process_group("gloo")
+        n = %d
+        pts = np.arange(n * 3, dtype=np.float64).reshape(n, 3)
+        calls = []
+        def fn(block, base):
+            calls.append((base, len(block)))
+            return block.sum(axis=1) * 1000.0 + base + np.arange(len(block))      # depends on the GLOBAL index
+        out = rdist.sharded_map(pts, fn)
+        want = pts.sum(axis=1) * 1000.0 + np.arange(n)
+        lo, hi = rdist.shard_bounds(n, 2, dist.get_rank())
+        assert calls == ([(lo, hi - lo)] if hi > lo else []), calls
+        assert out.dtype == np.float64 and np.array_equal(out, want), (out, want)
+        dist.barrier(); dist.destroy_process_group()
+        print("rank ok")
+    """ % (ROOT, n)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("rank ok") == 2

@@ -1,0 +1,72 @@
+"""GPU tests of the drop-in model objects (the reference's Python method signatures) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from roundtrip_amd import Generator, Roundtrip, RoundtripModel, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_estimate(model, g, y, centres, S, sd, scale, df, log):
+    xs = model.engine.draw_samples(centres, S, scale, df, seed=model.is_seed).astype(np.float64)
+    og = c_oracle.OracleMlp(g.weights, g.biases, g.alpha)
+    return c_oracle.is_estimate_given_samples(og, y, centres, xs, sd, scale, df, log, c_oracle.ORDER_KERNEL, 8)
+
+
+def test_v2_estimate_px_with_IS(tmp_path):
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    params = dict(dataset="indep_gmm", output_dir=str(tmp_path), x_dim=2, z_dim=2, g_units=[512] * 10,
+                  e_units=[256] * 10, dz_units=[128, 128], dx_units=[256] * 4, save_model=False, sd_x=0.05,
+                  scale=0.5, sample_size=20000, lr=2e-4, alpha=10, beta=1, gamma=0, g_d_freq=1)
+    m = Roundtrip(params, timestamp="gpu", random_seed=123)
+    x = np.random.RandomState(0).standard_normal((9, 2)) * 0.2
+    S = 3000
+    got = m.estimate_px_with_IS(x, sd_x=params["sd_x"], scale=params["scale"], sample_size=S)
+    assert got.shape == (9,) and got.dtype == np.float64
+    z = m.e_net(x)                                            # self.e_net(x_points), roundtrip.py:283
+    assert z.shape == (9, 2) and z.dtype == np.float32
+    want = _oracle_estimate(m, m.g_net, x, z, S, 0.05, 0.5, 1.0, True)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    lin = m.estimate_px_with_IS(x, sd_x=0.05, scale=0.5, sample_size=S, log=False)
+    np.testing.assert_allclose(np.log(lin), got, rtol=1e-12)
+    # same call => same answer (the reference reseeds with 0 at every call, roundtrip.py:230)
+    assert np.array_equal(got, m.estimate_px_with_IS(x, sd_x=0.05, scale=0.5, sample_size=S, bs=7))
+    # new weights are picked up
+    m.g_net.set_weights([w * 0.5 for w in m.g_net.weights], m.g_net.biases)
+    again = m.estimate_px_with_IS(x, sd_x=0.05, scale=0.5, sample_size=S)
+    assert not np.array_equal(again, got)
+    np.testing.assert_allclose(again, _oracle_estimate(m, m.g_net, x, z, S, 0.05, 0.5, 1.0, True), rtol=1e-12)
+    # v1 spelling on the v2 object, with the save side effect (main_density_est.py:346-347)
+    py = m.estimate_py_with_IS(x, 3, sd_y=0.05, scale=0.5, sample_size=S)
+    assert np.array_equal(py, again)
+    assert np.array_equal(np.load("%s/py_est_at_epoch3.npy" % m.save_dir), py)
+
+
+def test_v1_model(tmp_path, monkeypatch):
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(1234)
+    g = Generator(3, 6, "g_net", nb_layers=10, nb_units=512, rng=rng)      # main_density_est.py:447-448
+    h = Generator(6, 3, "h_net", nb_layers=10, nb_units=256, rng=rng)
+    m = RoundtripModel(g, h, None, None, None, None, "arem", None, 64, 10.0, 10.0, 3, False)
+    y = np.random.RandomState(42).standard_normal((5, 6)) * 0.05
+    xh = m.predict_x(y)                                                     # :237-249
+    assert xh.dtype == np.float64 and xh.shape == (5, 3)
+    oh = c_oracle.OracleMlp(h.weights, h.biases)
+    assert np.array_equal(xh.astype(np.float32), oh.forward(y.astype(np.float32), c_oracle.ORDER_KERNEL))
+    yy = m.predict_y(xh)
+    og = c_oracle.OracleMlp(g.weights, g.biases)
+    assert np.array_equal(yy.astype(np.float32), og.forward(xh.astype(np.float32), c_oracle.ORDER_KERNEL))
+    S = 2000
+    got = m.estimate_py_with_IS(y, 5, sd_y=0.1, scale=0.1, sample_size=S, save=True)     # df = self.df = 3
+    want = _oracle_estimate(m, g, y, xh.astype(np.float32), S, 0.1, 0.1, 3.0, True)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    assert np.array_equal(np.load("%s/py_est_at_epoch5.npy" % m.save_dir), got)
+    assert len(os.listdir(m.save_dir)) == 1
+    m.estimate_py_with_IS(y, 6, sample_size=64, save=False)
+    assert len(os.listdir(m.save_dir)) == 1

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP path, called through the C ABI (roundtrip_amd._lib.Engine is a thin ctypes
+layer over include/rt_is.h), against the CPU oracle on the same seeded inputs, against the committed golden
+vectors, and through size-independent properties at BASELINE sizes.
+
+Tolerances (north_star: 1e-4 relative on log p(y)):
+  * MLP forward vs the oracle run in the kernel's summation order: BIT-EXACT (the fp32 MFMA is a k-ordered
+    fmaf chain);
+  * log p(y) vs the oracle in kernel order: 1e-12 relative (only fp64 rounding of the scoring differs);
+  * log p(y) vs the oracle in natural order / the numpy golden vectors: 1e-6 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from oracle import c_oracle, is_ref
+from roundtrip_amd import _lib
+
+from test_oracle import GOLDEN, GOLDEN_NAMES, assert_linear_close, gaussian_logpdf, golden_nets, golden_samples, linear_g
+
+pytestmark = pytest.mark.gpu
+
+G, H = _lib.RT_MLP_G, _lib.RT_MLP_H
+
+# (dx, dy) of the BASELINE configs: 2/2, AReM 3/6, CASP 5/9, BANK 8/17, HEPMASS 8/21, YearPredictionMSD 20/90
+DIMS = [(2, 2), (3, 6), (5, 9), (8, 17), (8, 21), (20, 90)]
+
+
+def reference_samples(xhat, scale, df, S, seed=0):
+    """Draws as the reference does (main_density_est.py:316-318) with numpy's legacy global RNG."""
+    np.random.seed(seed)
+    return np.stack([is_ref.sample_from_qx(xhat[n].astype(np.float64), xhat.shape[1], scale, df, S)
+                     for n in range(xhat.shape[0])])
+
+
+@pytest.mark.parametrize("dx,dy", DIMS)
+def test_mlp_forward_bit_exact(engine, make_nets, dx, dy):
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og, oh = c_oracle.OracleMlp(gw, gb), c_oracle.OracleMlp(hw, hb)
+    rng = np.random.RandomState(dx * 100 + dy)
+    for n in (1, 63, 64, 65, 200):                      # ragged row counts around the 64-row pass
+        x = (rng.standard_normal((n, dx)) * 2).astype(np.float32)
+        got = engine.mlp_forward(G, x)
+        assert np.array_equal(got, og.forward(x, c_oracle.ORDER_KERNEL, nthreads=8))
+        nat = og.forward(x, c_oracle.ORDER_NATURAL, nthreads=8)
+        assert np.abs(got - nat).max() <= 2e-6 * np.abs(nat).max()
+    y = rng.standard_normal((130, dy)).astype(np.float32)
+    assert np.array_equal(engine.mlp_forward(H, y), oh.forward(y, c_oracle.ORDER_KERNEL, nthreads=8))
+    assert engine.mlp_forward(G, np.zeros((0, dx), np.float32)).shape == (0, dy)
+
+
+def test_mlp_forward_heavy_tails_and_specials(engine, make_nets):
+    """Cauchy proposals routinely give |x| ~ 1e4..1e6; inf/NaN inputs must propagate, not crash."""
+    gw, gb, _, _ = make_nets(2, 2)
+    engine.set_mlp(G, gw, gb)
+    og = c_oracle.OracleMlp(gw, gb)
+    x = np.array([[1e4, -3e5], [1e8, 1e-8], [0, 0], [-0.0, 1e-30], [1e30, -1e30], [np.inf, 1.0], [np.nan, 0.0]],
+                 np.float32)
+    got = engine.mlp_forward(G, x)
+    want = og.forward(x, c_oracle.ORDER_KERNEL)
+    assert np.array_equal(got[:5], want[:5])
+    assert not np.isfinite(got[5]).any() and np.isnan(got[6]).all()
+
+
+@pytest.mark.parametrize("hid,nl", [(128, 1), (128, 3), (256, 2), (512, 4)])
+def test_other_depths_and_widths(engine, hid, nl):
+    from conftest import glorot
+    ws, bs = glorot([3] + [hid] * nl + [5], 9, 10)
+    engine.set_mlp(G, ws, bs)
+    x = np.random.RandomState(1).standard_normal((100, 3)).astype(np.float32)
+    assert np.array_equal(engine.mlp_forward(G, x), c_oracle.OracleMlp(ws, bs).forward(x, c_oracle.ORDER_KERNEL))
+
+
+@pytest.mark.parametrize("dx,dy", DIMS)
+@pytest.mark.parametrize("log", [True, False])
+def test_given_samples_match_oracle(engine, make_nets, dx, dy, log):
+    """The reference's own draws (numpy legacy RNG, float64) scored on the GPU and by the oracle."""
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og = c_oracle.OracleMlp(gw, gb)
+    y = np.random.RandomState(42).standard_normal((5, dy)) * 0.3
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    S = 777                                            # not a multiple of 64: ragged last pass
+    xs = reference_samples(xhat, 0.1, 1, S)
+    got = engine.is_estimate_given_samples(y, xhat, xs, 0.1, 0.1, 1.0, log=log)
+    exact = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.1, 0.1, 1.0, log, c_oracle.ORDER_KERNEL, 8)
+    nat = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.1, 0.1, 1.0, log, c_oracle.ORDER_NATURAL, 8)
+    if log:
+        np.testing.assert_allclose(got, exact, rtol=1e-12)
+        np.testing.assert_allclose(got, nat, rtol=1e-6)
+    else:
+        assert_linear_close(got, exact, 1e-12)
+        assert_linear_close(got, nat, 1e-6)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_vectors(engine, name):
+    f = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gw, gb, hw, hb = golden_nets(f)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    xhat = engine.mlp_forward(H, f["y"].astype(np.float32))
+    np.testing.assert_allclose(xhat, f["xhat"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(engine.mlp_forward(G, f["xhat"]), f["g_of_xhat"], rtol=2e-5, atol=1e-7)
+    xs = golden_samples(f)
+    sd, scale, df = float(f["sd"]), float(f["scale"]), float(f["df"])
+    got = engine.is_estimate_given_samples(f["y"], f["xhat"], xs, sd, scale, df, log=True)
+    np.testing.assert_allclose(got, f["log_est"], rtol=1e-6)
+    lin = engine.is_estimate_given_samples(f["y"], f["xhat"], xs, sd, scale, df, log=False)
+    assert_linear_close(lin, f["lin_est"], 1e-6)
+
+
+@pytest.mark.parametrize("dx,dy,df", [(2, 2, 1.0), (3, 6, 1.0), (20, 90, 1.0), (2, 2, 3.0), (5, 9, 2.5)])
+def test_rng_mode_matches_oracle_on_the_same_draws(engine, make_nets, dx, dy, df):
+    """rt_is_estimate (on-GPU Philox draws) == oracle scoring of rt_draw_samples' output."""
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og = c_oracle.OracleMlp(gw, gb)
+    y = np.random.RandomState(3).standard_normal((6, dy)) * 0.3
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    S = 1500
+    got = engine.is_estimate(y, xhat, S, 0.1, 0.1, df, seed=7, y_index_base=100)
+    xs = engine.draw_samples(xhat, S, 0.1, df, seed=7, y_index_base=100)
+    want = c_oracle.is_estimate_given_samples(og, y, xhat, xs.astype(np.float64), 0.1, 0.1, df, True,
+                                              c_oracle.ORDER_KERNEL, 8)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    if df == float(int(df)):
+        # the oracle's restatement of the sampler agrees to a few float32 ulp (libm vs device logf/sincosf)
+        xo = c_oracle.draw_samples(xhat, 100, S, 0.1, df, 7)
+        close = np.isclose(xs, xo, rtol=2e-3, atol=1e-6)
+        assert close.mean() > 0.9999
+
+
+def test_sampler_statistics(engine, make_nets):
+    """df = 1: each coordinate of (x - xhat)/scale is standard Cauchy, the radius has the multivariate-Cauchy
+    law; df = 3, 2.5: Student-t marginals (the 2.5 case exercises the gamma sampler)."""
+    gw, gb, _, _ = make_nets(2, 2)
+    engine.set_mlp(G, gw, gb)
+    xhat = np.array([[0.5, -1.0]], np.float32)
+    n = 200000
+    for df in (1.0, 3.0, 2.5):
+        xs = engine.draw_samples(xhat, n, 0.5, df, seed=0)[0].astype(np.float64)
+        u = (xs - xhat[0]) / 0.5
+        for d in range(2):
+            ks = stats.kstest(u[:, d], stats.t(df).cdf)
+            assert ks.pvalue > 1e-3, (df, d, ks)
+        # radial law of a bivariate t: r^2/2 ~ F(2, df)
+        ks = stats.kstest((u ** 2).sum(axis=1) / 2.0, stats.f(2, df).cdf)
+        assert ks.pvalue > 1e-3, (df, ks)
+    a = engine.draw_samples(xhat, 1000, 0.5, 1.0, seed=0)
+    assert np.array_equal(a, engine.draw_samples(xhat, 1000, 0.5, 1.0, seed=0))
+    assert not np.array_equal(a, engine.draw_samples(xhat, 1000, 0.5, 1.0, seed=1))
+    assert not np.array_equal(a, engine.draw_samples(xhat, 1000, 0.5, 1.0, seed=0, y_index_base=1))
+
+
+def test_sharding_and_chunking_invariance(engine, make_nets):
+    """Results depend on the GLOBAL query index only: evaluating a block with y_index_base = its offset is
+    bit-identical to evaluating everything at once (what makes any GPU count give the same answer), and the
+    sample-chunk decomposition (small N => many chunks per point) does not change the value beyond fp64
+    re-association."""
+    gw, gb, hw, hb = make_nets(2, 2)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    y = np.random.RandomState(5).standard_normal((600, 2)) * 0.2
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    S = 640
+    full = engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0)
+    assert np.array_equal(full, engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0))     # deterministic
+    parts = [engine.is_estimate(y[lo:hi], xhat[lo:hi], S, 0.05, 0.5, 1.0, seed=0, y_index_base=lo)
+             for lo, hi in ((0, 300), (300, 600))]
+    np.testing.assert_allclose(np.concatenate(parts), full, rtol=1e-13)
+    one = engine.is_estimate(y[7:8], xhat[7:8], S, 0.05, 0.5, 1.0, seed=0, y_index_base=7)   # 1 point: 10 chunks
+    np.testing.assert_allclose(one, full[7:8], rtol=1e-13)
+
+
+@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 129])
+def test_ragged_sample_counts(engine, make_nets, S):
+    gw, gb, hw, hb = make_nets(3, 6)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og = c_oracle.OracleMlp(gw, gb)
+    y = np.random.RandomState(8).standard_normal((3, 6)) * 0.1
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    got = engine.is_estimate(y, xhat, S, 0.5, 0.1, 1.0, seed=1)
+    xs = engine.draw_samples(xhat, S, 0.1, 1.0, seed=1).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.1, 1.0, True, c_oracle.ORDER_KERNEL)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_empty_and_error_paths(engine, make_nets):
+    gw, gb, hw, hb = make_nets(2, 2)
+    fresh = _lib.Engine(0)
+    try:
+        with pytest.raises(_lib.RtError):                       # MLP not set
+            fresh.is_estimate(np.zeros((1, 2)), np.zeros((1, 2), np.float32), 10, 0.1, 0.1)
+        with pytest.raises(_lib.RtError):                       # hidden width not supported by the fused kernel
+            fresh.set_mlp(G, [np.zeros((2, 100), np.float32), np.zeros((100, 2), np.float32)],
+                          [np.zeros(100, np.float32), np.zeros(2, np.float32)])
+        with pytest.raises(_lib.RtError):                       # alpha outside [0, 1]
+            fresh.set_mlp(G, gw, gb, alpha=1.5)
+    finally:
+        fresh.close()
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    assert engine.is_estimate(np.zeros((0, 2)), np.zeros((0, 2), np.float32), 100, 0.1, 0.1).shape == (0,)
+    y, xh = np.zeros((2, 2)), np.zeros((2, 2), np.float32)
+    for bad in (dict(sample_size=0), dict(sd_y=0.0), dict(scale=-1.0), dict(df=0.0)):
+        kw = dict(sample_size=10, sd_y=0.1, scale=0.1, df=1.0)
+        kw.update(bad)
+        with pytest.raises(_lib.RtError):
+            engine.is_estimate(y, xh, **kw)
+    with pytest.raises(ValueError):
+        engine.is_estimate(np.zeros((2, 3)), xh, 10, 0.1, 0.1)
+
+
+def test_far_points_underflow_like_the_reference(engine, make_nets):
+    """log=False far from the data: the reference's linear-space product underflows to exactly 0
+    (main_density_est.py:290,344-345); log=True stays finite."""
+    gw, gb, hw, hb = make_nets(2, 2)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    y = np.array([[300.0, -300.0], [0.01, 0.02]])
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    lin = engine.is_estimate(y, xhat, 500, 0.05, 0.5, 1.0, log=False)
+    lg = engine.is_estimate(y, xhat, 500, 0.05, 0.5, 1.0, log=True)
+    assert lin[0] == 0.0 and lin[1] > 0.0 and np.isfinite(lg).all() and lg[0] < -1e6
+    np.testing.assert_allclose(np.log(lin[1]), lg[1], rtol=1e-12)
+
+
+def test_analytic_linear_generator_known_answer_on_gpu(engine):
+    """p(y) = N(y; b, A^T A + sd^2 I) for an exactly linear G (see tests/test_oracle.py); on-GPU draws, S large."""
+    dx, dy, sd = 1, 3, 0.5
+    A = np.array([[1.0, 0.5, -0.25]], np.float32)
+    b = np.array([0.1, -0.2, 0.3], np.float32)
+    ws, bs = linear_g(dx, dy, 128, 3, A, b)
+    engine.set_mlp(G, ws, bs)
+    cov = A.T.astype(np.float64) @ A + sd * sd * np.eye(dy)
+    ys = np.array([[0.3, -0.1, 0.2], [1.0, 0.5, -0.5], [-0.4, 0.0, 0.9]])
+    post_cov = np.linalg.inv(np.eye(dx) + A.astype(np.float64) @ A.T / sd ** 2)
+    centres = np.stack([post_cov @ (A.astype(np.float64) @ (y - b)) / sd ** 2 for y in ys]).astype(np.float32)
+    want = np.array([gaussian_logpdf(y, b.astype(np.float64), cov) for y in ys])
+    for df in (1.0, 3.0):
+        got = engine.is_estimate(ys, centres, 400000, sd, 1.0, df, seed=3)
+        assert np.abs(got - want).max() < 0.01, (df, got, want)
+
+
+def test_full_size_properties(engine, make_nets):
+    """BASELINE config 2 at full size (100x100 grid, S = 10000, log=False): too large for the oracle, so
+    check size-independent properties: exp(log-mode) == linear-mode, rank-sharding invariance on a slice,
+    and oracle agreement on a few points re-evaluated alone."""
+    gw, gb, hw, hb = make_nets(2, 2, biased=False)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    grid = is_ref.create_2d_grid_data(-5, 5, -5, 5, n=100)[2]
+    xhat = engine.mlp_forward(H, grid.astype(np.float32))
+    S = 10000
+    lin = engine.is_estimate(grid, xhat, S, 0.1, 0.5, 1.0, log=False)
+    lg = engine.is_estimate(grid, xhat, S, 0.1, 0.5, 1.0, log=True)
+    assert lin.shape == (10000,) and np.isfinite(lg).all()
+    assert_linear_close(lin, np.exp(lg), 1e-12)
+    idx = np.array([0, 4999, 5050, 9999])
+    og = c_oracle.OracleMlp(gw, gb)
+    for i in idx:
+        xs = engine.draw_samples(xhat[i:i + 1], S, 0.5, 1.0, seed=0, y_index_base=int(i)).astype(np.float64)
+        want = c_oracle.is_estimate_given_samples(og, grid[i:i + 1], xhat[i:i + 1], xs, 0.1, 0.5, 1.0, True,
+                                                  c_oracle.ORDER_KERNEL, 8)
+        np.testing.assert_allclose(lg[i], want[0], rtol=1e-12)
