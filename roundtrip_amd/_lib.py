@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_is.so")
+# RT_IS_LIB points the binding at a diagnostic build of the same library (scripts/stamps.py); default: in-tree
+LIB_PATH = os.environ.get("RT_IS_LIB") or os.path.join(_HERE, "librt_is.so")
 
 RT_MLP_G = 0
 RT_MLP_H = 1

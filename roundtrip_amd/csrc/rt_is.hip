@@ -50,6 +50,20 @@ struct MlpArgs {
     float alpha;
 };
 
+// Diagnostic build only (-DRT_STAMPS, scripts/stamps.py): per-phase s_memtime sums of workgroup 0's waves.
+// In the shipped library none of this exists.
+#ifdef RT_STAMPS
+__device__ unsigned long long g_stamps[4 * 8];
+struct Stamps { unsigned long long t, acc[8]; };
+#define ST_PARAM , Stamps& st
+#define ST_ARG , st
+#define ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st.acc[i] += n_ - st.t; st.t = n_; }
+#else
+#define ST_PARAM
+#define ST_ARG
+#define ST(i)
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // LDS activation image.  Row-block kg holds k = 8kg .. 8kg+7 for the 64 samples of the pass:
 //   byte offset of (kg, sample s, half hh in {0,1}, element e in 0..3) =
@@ -84,39 +98,85 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][2], const f32x4 (&
 //          between feature tiles = 64 f32x4
 //   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 2048 B,
 //          sample tile stride 1024 B
-// Weights and activations for k-group kg+1 are loaded while k-group kg's 8*NFT MFMAs issue.
+#ifndef RT_ABL
+#define RT_ABL 0   // diagnostic ablations (never set in the shipped build): 1 = no weight loads, 2 = no LDS reads in the K loop
+#endif
+template <int NFT, int ABL = 0>
+__device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[2], const f32x4* __restrict__ wl,
+                                           int wstride, const char* bl, int kg) {
+    const f32x4* w = wl + (size_t)kg * wstride;
+    const char* l = bl + kg * 2048;
+    if (!(ABL & 1)) {
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) a[ft] = w[ft * 64];
+    } else {
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) asm volatile("" : "+v"(a[ft]));
+    }
+    if (!(ABL & 2)) {
+        b[0] = *(const f32x4*)(l);
+        b[1] = *(const f32x4*)(l + 1024);
+    } else {
+        asm volatile("" : "+v"(b[0]), "+v"(b[1]));
+    }
+}
+
+// Short / odd K (layer 0: K = padded input dim): no software pipelining.
+template <int NFT>
+__device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][2], const f32x4* __restrict__ wl,
+                                                 int ftt, int nkg, const char* bl) {
+    f32x4 a[NFT], b[2];
+#pragma unroll 1
+    for (int kg = 0; kg < nkg; ++kg) {
+        load_group<NFT>(a, b, wl, ftt * 64, bl, kg);
+        mfma_group<NFT>(acc, a, b);
+    }
+}
+
+// One pipeline stage: request the operands of a later k-group into (an, bn) and run the 8*NFT MFMAs of
+// the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
+// the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
+// behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
+template <int NFT>
+__device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][2], f32x4 (&an)[NFT], f32x4 (&bn)[2],
+                                           const f32x4 (&ac)[NFT], const f32x4 (&bc)[2],
+                                           const f32x4* __restrict__ wl, int wstride, const char* bl, int kgn) {
+    load_group<NFT, RT_ABL>(an, bn, wl, wstride, bl, kgn);
+    mfma_group<NFT>(acc, ac, bc);
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NFT - NFT - 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
+// MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
 template <int NFT>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][2], const f32x4* __restrict__ wl,
                                           int ftt, int nkg, const char* bl) {
-    f32x4 a0[NFT], a1[NFT], b0[2], b1[2];
+    f32x4 a0[NFT], a1[NFT], a2[NFT], a3[NFT], b0[2], b1[2], b2[2], b3[2];
     const int wstride = ftt * 64;
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) a0[ft] = wl[ft * 64];
-    b0[0] = *(const f32x4*)(bl);
-    b0[1] = *(const f32x4*)(bl + 1024);
-    int kg = 0;
+    const int lastg = nkg - 1;
+    load_group<NFT>(a0, b0, wl, wstride, bl, 0);
+    load_group<NFT>(a1, b1, wl, wstride, bl, 1);
+    load_group<NFT>(a2, b2, wl, wstride, bl, 2);
+    if (RT_ABL) load_group<NFT>(a3, b3, wl, wstride, bl, 3);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (; kg + 2 <= nkg; kg += 2) {
-        {
-            const f32x4* w1 = wl + (size_t)(kg + 1) * wstride;
-            const char* l1 = bl + (kg + 1) * 2048;
-#pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) a1[ft] = w1[ft * 64];
-            b1[0] = *(const f32x4*)(l1);
-            b1[1] = *(const f32x4*)(l1 + 1024);
-        }
-        mfma_group<NFT>(acc, a0, b0);
-        if (kg + 2 < nkg) {
-            const f32x4* w2 = wl + (size_t)(kg + 2) * wstride;
-            const char* l2 = bl + (kg + 2) * 2048;
-#pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) a0[ft] = w2[ft * 64];
-            b0[0] = *(const f32x4*)(l2);
-            b0[1] = *(const f32x4*)(l2 + 1024);
-        }
-        mfma_group<NFT>(acc, a1, b1);
+    for (int kg = 0; kg < nkg; kg += 4) {
+        pipe_stage<NFT>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
+        pipe_stage<NFT>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
+        pipe_stage<NFT>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
+        pipe_stage<NFT>(acc, a2, b2, a3, b3, wl, wstride, bl, min(kg + 6, lastg));
     }
-    if (kg < nkg) mfma_group<NFT>(acc, a0, b0);
 }
 
 // Hidden-layer epilogue: act = lrelu(acc + bias), written in the next layer's B-operand image.
@@ -184,7 +244,7 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
 // part[(w*out_dim + d)*64 + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 256 threads.
 template <int HID>
-__device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane) {
+__device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane ST_PARAM) {
     constexpr int NFT = HID / 128;
     constexpr int FTT = HID / 32;
     const int h = lane >> 5, j = lane & 31;
@@ -196,16 +256,21 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
 
-    gemm_tile<NFT>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
-                   x0 + act_off(0, j, h));
+    gemm_tile_simple<NFT>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
+                          x0 + act_off(0, j, h));
+    ST(1)
     const int nhid = m.n_layers - 1;
     for (int l = 0; l < nhid; ++l) {
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
+        ST(2)
         store_act<NFT>(acc, m.bp[l], m.alpha, act, wave, lane);
+        ST(3)
         __syncthreads();
+        ST(4)
         if (l + 1 < nhid)
             gemm_tile<NFT>(acc, (const f32x4*)m.wp[l + 1] + (wave * NFT) * 64 + lane, FTT, HID / 8,
                            act + act_off(0, j, h));
+        ST(5)
     }
     float* part = (float*)act;
     switch (m.nt_out) {
@@ -214,6 +279,7 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
         case 3: last_layer<3>(m, HID / 32, act, part, wave, lane); break;
         default: last_layer<4>(m, HID / 32, act, part, wave, lane); break;
     }
+    ST(6)
 }
 
 __device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
@@ -377,6 +443,11 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     // zero the padded rows of the x0 image once: rows >= dx are never written again
     for (int i = tid; i < m.k0 * 16; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef RT_STAMPS
+    Stamps st;
+    for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+    st.t = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
         const int64_t n = unit / a.nchunks;
         const int c = (int)(unit - n * a.nchunks);
@@ -408,8 +479,9 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
                             });
             }
             __syncthreads();
+            ST(0)
             // ---- B. G forward ---------------------------------------------------------------------
-            mlp_core<HID>(m, x0, act, wave, lane);
+            mlp_core<HID>(m, x0, act, wave, lane ST_ARG);
             // ---- C. score: thread (s, p) handles dims d = p, p+4, ... ------------------------------
             double se = 0.0;
             for (int d = p; d < dy; d += 4) {
@@ -445,6 +517,10 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             if (lane == 0) { a.partial[2 * unit] = M; a.partial[2 * unit + 1] = t; }
         }
     }
+#ifdef RT_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[wave * 8 + i], st.acc[i]);
+#endif
 }
 
 __global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, double logS,
@@ -484,7 +560,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
             *(float*)(x0 + act_off(d >> 3, lane, (d >> 2) & 1) + 4 * (d & 3)) =
                 (row < N) ? in[row * m.in_dim + d] : 0.0f;
         __syncthreads();
-        mlp_core<HID>(m, x0, act, wave, lane);
+#ifdef RT_STAMPS
+        Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+#endif
+        mlp_core<HID>(m, x0, act, wave, lane ST_ARG);
         if (row < N)
             for (int d = wave; d < m.out_dim; d += 4) out[row * m.out_dim + d] = mlp_out(m, part, d, lane);
     }
@@ -944,6 +1023,20 @@ int rt_reset_counters(rt_ctx* ctx) {
     ctx->evals_acc = 0;
     return RT_OK;
 }
+
+#ifdef RT_STAMPS
+int rt_debug_stamps(rt_ctx* ctx, unsigned long long* out32, int reset) {
+    if (!ctx || !out32) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+    }
+    return RT_OK;
+}
+#endif
 
 int rt_device_cu_count(rt_ctx* ctx, int* out) {
     if (!ctx || !out) return RT_EINVAL;
