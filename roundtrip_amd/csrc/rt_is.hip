@@ -22,6 +22,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <new>
@@ -33,7 +34,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int MS = 64;          // samples per workgroup pass
 constexpr int NTHREADS = 256;   // 4 waves, one per SIMD
 constexpr int MAX_IN = 128;     // max input dim of a fused MLP (also bounded by the LDS budget)
 constexpr int LDS_MAX = 160 * 1024;
@@ -65,47 +65,52 @@ struct Stamps { unsigned long long t, acc[8]; };
 #endif
 
 // ----------------------------------------------------------------------------------------------
-// LDS activation image.  Row-block kg holds k = 8kg .. 8kg+7 for the 64 samples of the pass:
+// LDS activation image.  A workgroup pass handles MS = 32*NST samples (NST = sample tiles per wave).
+// Row-block kg holds k = 8kg .. 8kg+7 for the MS samples of the pass:
 //   byte offset of (kg, sample s, half hh in {0,1}, element e in 0..3) =
-//       ((kg*64 + s)*2 + (hh ^ swz(s)))*16 + 4e          holding k = 8kg + 4hh + e
+//       ((kg*MS + s)*2 + (hh ^ swz(s)))*16 + 4e          holding k = 8kg + 4hh + e
 // swz() makes the ds_read_b128 of a 32-lane half (stride 32 B between samples) and the
 // ds_write_b128 of the epilogue conflict-free (bank rules: MI355X_MICROARCH.md, LDS section).
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int act_swz(int s) { return ((s >> 3) ^ (s >> 2)) & 1; }
+template <int MS>
 __device__ __forceinline__ int act_off(int kg, int s, int hh) {
-    return ((kg * 64 + s) * 2 + (hh ^ act_swz(s))) * 16;
+    return ((kg * MS + s) * 2 + (hh ^ act_swz(s))) * 16;
 }
 
 // ----------------------------------------------------------------------------------------------
-// One k-group (8 k values = 4 MFMA k-steps of 2) for NFT feature tiles x 2 sample tiles.
+// One k-group (8 k values = 4 MFMA k-steps of 2) for NFT feature tiles x NST sample tiles.
 // MFMA 32x32x2 operand maps (cdna_hip_programming.md §3): lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // here lane half h at step e handles k = 8kg + 4h + e (any k order is a valid sum).
 // ----------------------------------------------------------------------------------------------
-template <int NFT>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][2], const f32x4 (&a)[NFT],
-                                           const f32x4 (&b)[2]) {
+template <int NFT, int NST>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
+                                           const f32x4 (&b)[NST]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < NST; ++st)
                 acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][e], b[st][e], acc[ft][st], 0, 0, 0);
 }
 
 // acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
 //   wl   : this lane's packed A operands for (kg = first, ft = 0); stride between kg = ftt*64 f32x4,
 //          between feature tiles = 64 f32x4
-//   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 2048 B,
+//   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 64*NST*16 B,
 //          sample tile stride 1024 B
+#ifndef RT_SCHED
+#define RT_SCHED 0   // placement of the K loop's memory instructions among the MFMAs (see pipe_stage)
+#endif
 #ifndef RT_ABL
 #define RT_ABL 0   // diagnostic ablations (never set in the shipped build): 1 = no weight loads, 2 = no LDS reads in the K loop
 #endif
-template <int NFT, int ABL = 0>
-__device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[2], const f32x4* __restrict__ wl,
+template <int NFT, int NST, int ABL = 0>
+__device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], const f32x4* __restrict__ wl,
                                            int wstride, const char* bl, int kg) {
     const f32x4* w = wl + (size_t)kg * wstride;
-    const char* l = bl + kg * 2048;
+    const char* l = bl + kg * (1024 * NST);
     if (!(ABL & 1)) {
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) a[ft] = w[ft * 64];
@@ -113,118 +118,190 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[2], const
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) asm volatile("" : "+v"(a[ft]));
     }
-    if (!(ABL & 2)) {
-        b[0] = *(const f32x4*)(l);
-        b[1] = *(const f32x4*)(l + 1024);
-    } else {
-        asm volatile("" : "+v"(b[0]), "+v"(b[1]));
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        if (!(ABL & 2)) b[st] = *(const f32x4*)(l + 1024 * st);
+        else asm volatile("" : "+v"(b[st]));
     }
 }
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
-template <int NFT>
-__device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][2], const f32x4* __restrict__ wl,
+template <int NFT, int NST>
+__device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const f32x4* __restrict__ wl,
                                                  int ftt, int nkg, const char* bl) {
-    f32x4 a[NFT], b[2];
+    f32x4 a[NFT], b[NST];
 #pragma unroll 1
     for (int kg = 0; kg < nkg; ++kg) {
-        load_group<NFT>(a, b, wl, ftt * 64, bl, kg);
-        mfma_group<NFT>(acc, a, b);
+        load_group<NFT, NST>(a, b, wl, ftt * 64, bl, kg);
+        mfma_group<NFT, NST>(acc, a, b);
     }
 }
 
-// One pipeline stage: request the operands of a later k-group into (an, bn) and run the 8*NFT MFMAs of
-// the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
+// One pipeline stage: request the operands of a later k-group into (an, bn) and run the 4*NFT*NST MFMAs
+// of the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
 // the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
 // behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
-template <int NFT>
-__device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][2], f32x4 (&an)[NFT], f32x4 (&bn)[2],
-                                           const f32x4 (&ac)[NFT], const f32x4 (&bc)[2],
+template <int NFT, int NST>
+__device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
+                                           const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
                                            const f32x4* __restrict__ wl, int wstride, const char* bl, int kgn) {
-    load_group<NFT, RT_ABL>(an, bn, wl, wstride, bl, kgn);
-    mfma_group<NFT>(acc, ac, bc);
+    load_group<NFT, NST, RT_ABL>(an, bn, wl, wstride, bl, kgn);
+    mfma_group<NFT, NST>(acc, ac, bc);
+    constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
+#if RT_SCHED == 0
 #pragma unroll
     for (int i = 0; i < NFT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NST; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NFT - NFT - 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NFT - NST, 0);
+#elif RT_SCHED == 1   // memory instructions spread evenly over the stage
+    constexpr int GAP = NM / (NFT + NST);
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NFT + NST), 0);
+#elif RT_SCHED == 2   // two memory instructions behind each of the first MFMAs
+#pragma unroll
+    for (int i = 0; i < NFT / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NST, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NFT / 2 - 1, 0);
+#elif RT_SCHED == 3   // LDS reads first (short latency chain), weights later
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NST - 4 * NFT, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Requests the weight operands of the first three k-groups of a layer.  Weights do not depend on the
+// activations, so this is issued BEFORE the previous layer's epilogue and barriers and lands behind them.
+template <int NFT>
+__device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f32x4 (&a2)[NFT],
+                                           const f32x4* __restrict__ wl, int wstride) {
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        a0[ft] = wl[ft * 64];
+        a1[ft] = wl[(size_t)wstride + ft * 64];
+        a2[ft] = wl[(size_t)2 * wstride + ft * 64];
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
 // MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
-template <int NFT>
-__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][2], const f32x4* __restrict__ wl,
+// a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
+template <int NFT, int NST>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
+                                          f32x4 (&a2)[NFT], const f32x4* __restrict__ wl,
                                           int ftt, int nkg, const char* bl) {
-    f32x4 a0[NFT], a1[NFT], a2[NFT], a3[NFT], b0[2], b1[2], b2[2], b3[2];
+    f32x4 a3[NFT], b0[NST], b1[NST], b2[NST], b3[NST];
     const int wstride = ftt * 64;
     const int lastg = nkg - 1;
-    load_group<NFT>(a0, b0, wl, wstride, bl, 0);
-    load_group<NFT>(a1, b1, wl, wstride, bl, 1);
-    load_group<NFT>(a2, b2, wl, wstride, bl, 2);
-    if (RT_ABL) load_group<NFT>(a3, b3, wl, wstride, bl, 3);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        b0[st] = *(const f32x4*)(bl + 1024 * st);
+        b1[st] = *(const f32x4*)(bl + 1024 * NST + 1024 * st);
+        b2[st] = *(const f32x4*)(bl + 2048 * NST + 1024 * st);
+    }
+    if (RT_ABL) load_group<NFT, NST>(a3, b3, wl, wstride, bl, 3);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int kg = 0; kg < nkg; kg += 4) {
-        pipe_stage<NFT>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
-        pipe_stage<NFT>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
-        pipe_stage<NFT>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
-        pipe_stage<NFT>(acc, a2, b2, a3, b3, wl, wstride, bl, min(kg + 6, lastg));
+        pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
+        pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
+        pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
+        pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(kg + 6, lastg));
     }
+}
+
+// This lane's biases for a hidden layer's epilogue: features 32FT + 8q + 4h + (0..3), FT = wave*NFT + ft.
+// Requested BEFORE the layer's K loop (sched_barrier keeps hipcc from sinking the loads to their use, where
+// each would expose an L2 round trip), consumed by store_act after it.
+template <int NFT>
+__device__ __forceinline__ void load_bias(f32x4 (&bv)[NFT][4], const float* __restrict__ bias, int wave, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bv[ft][q] = *(const f32x4*)(bias + 32 * (wave * NFT + ft) + 8 * q + 4 * h);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Hidden-layer epilogue: act = lrelu(acc + bias), written in the next layer's B-operand image.
 // C/D map of the 32x32 MFMA: lane (h, j): column j = sample; register r = row (r&3) + 8(r>>2) + 4h = feature.
 // Registers 4q..4q+3 of tile (FT, st) are features 32FT + 8q + 4h + (0..3) = next-layer k-group 4FT+q, half h.
-template <int NFT>
-__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][2], const float* __restrict__ bias,
+template <int NFT, int NST>
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], const f32x4 (&bv)[NFT][4],
                                           float alpha, char* act, int wave, int lane) {
+    constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
         const int FT = wave * NFT + ft;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *(const f32x4*)(bias + 32 * FT + 8 * q + 4 * h);
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = acc[ft][st][4 * q + e] + bv[e];
+                    const float t = acc[ft][st][4 * q + e] + bv[ft][q][e];
                     v[e] = fmaxf(t, alpha * t);
                 }
-                *(f32x4*)(act + act_off(4 * FT + q, 32 * st + j, h)) = v;
+                *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 * st + j, h)) = v;
             }
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NST; ++st)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
     }
 }
 
 // Output layer for NT feature tiles, K split over the four waves; partial sums go to
-// part[(wave*out_dim + d)*64 + s] (floats, aliases the activation image).
-template <int NT>
+// part[(wave*out_dim + d)*MS + s] (floats, aliases the activation image).
+template <int NT, int NST>
 __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, float* part, int wave,
                                            int lane) {
+    constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][NST];
 #pragma unroll
     for (int ft = 0; ft < NT; ++ft)
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NST; ++st)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
     const f32x4* wl = (const f32x4*)m.wp[m.n_layers - 1] + (size_t)(wave * kq) * NT * 64 + lane;
-    gemm_tile<NT>(acc, wl, NT, kq, act + act_off(wave * kq, j, h));
+    f32x4 a0[NT], a1[NT], a2[NT];
+    prefetch_a<NT>(a0, a1, a2, wl, NT * 64);
+    gemm_tile<NT, NST>(acc, a0, a1, a2, wl, NT, kq, act + act_off<MS>(wave * kq, j, h));
     __syncthreads();   // every wave is done reading the activation image
     const int od = m.out_dim;
 #pragma unroll
@@ -234,58 +311,65 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
             const int d = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (d < od) {
 #pragma unroll
-                for (int st = 0; st < 2; ++st) part[(wave * od + d) * 64 + 32 * st + j] = acc[ft][st][r];
+                for (int st = 0; st < NST; ++st) part[(wave * od + d) * MS + 32 * st + j] = acc[ft][st][r];
             }
         }
     __syncthreads();
 }
 
-// Runs the MLP on the 64 samples whose (padded) inputs sit in the x0 image.  On return
-// part[(w*out_dim + d)*64 + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
+// Runs the MLP on the MS samples whose (padded) inputs sit in the x0 image.  On return
+// part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 256 threads.
-template <int HID>
+template <int HID, int NST>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane ST_PARAM) {
     constexpr int NFT = HID / 128;
     constexpr int FTT = HID / 32;
+    constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
-    f32x16 acc[NFT][2];
+    f32x16 acc[NFT][NST];
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NST; ++st)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
 
-    gemm_tile_simple<NFT>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
-                          x0 + act_off(0, j, h));
+    f32x4 bv[NFT][4];
+    load_bias<NFT>(bv, m.bp[0], wave, lane);
+    gemm_tile_simple<NFT, NST>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
+                               x0 + act_off<MS>(0, j, h));
     ST(1)
     const int nhid = m.n_layers - 1;
+    f32x4 a0[NFT], a1[NFT], a2[NFT];
     for (int l = 0; l < nhid; ++l) {
+        const f32x4* wnext = (const f32x4*)m.wp[l + 1] + (wave * NFT) * 64 + lane;
+        if (l + 1 < nhid) prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
-        store_act<NFT>(acc, m.bp[l], m.alpha, act, wave, lane);
+        store_act<NFT, NST>(acc, bv, m.alpha, act, wave, lane);
+        if (l + 1 < nhid) load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
         ST(3)
         __syncthreads();
         ST(4)
         if (l + 1 < nhid)
-            gemm_tile<NFT>(acc, (const f32x4*)m.wp[l + 1] + (wave * NFT) * 64 + lane, FTT, HID / 8,
-                           act + act_off(0, j, h));
+            gemm_tile<NFT, NST>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h));
         ST(5)
     }
     float* part = (float*)act;
     switch (m.nt_out) {
-        case 1: last_layer<1>(m, HID / 32, act, part, wave, lane); break;
-        case 2: last_layer<2>(m, HID / 32, act, part, wave, lane); break;
-        case 3: last_layer<3>(m, HID / 32, act, part, wave, lane); break;
-        default: last_layer<4>(m, HID / 32, act, part, wave, lane); break;
+        case 1: last_layer<1, NST>(m, HID / 32, act, part, wave, lane); break;
+        case 2: last_layer<2, NST>(m, HID / 32, act, part, wave, lane); break;
+        case 3: last_layer<3, NST>(m, HID / 32, act, part, wave, lane); break;
+        default: last_layer<4, NST>(m, HID / 32, act, part, wave, lane); break;
     }
     ST(6)
 }
 
+template <int MS>
 __device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
     const int od = m.out_dim;
-    const float p0 = part[(0 * od + d) * 64 + s], p1 = part[(1 * od + d) * 64 + s];
-    const float p2 = part[(2 * od + d) * 64 + s], p3 = part[(3 * od + d) * 64 + s];
+    const float p0 = part[(0 * od + d) * MS + s], p1 = part[(1 * od + d) * MS + s];
+    const float p2 = part[(2 * od + d) * MS + s], p3 = part[(3 * od + d) * MS + s];
     return ((p0 + p1) + p2) + p3 + m.bp[m.n_layers - 1][d];
 }
 
@@ -394,7 +478,7 @@ struct IsArgs {
     int64_t N, S, y_index_base;
     int64_t n_units;
     int nchunks;            // chunks per query point
-    int chunk;              // samples per chunk (multiple of 64)
+    int64_t passes;         // ceil(S / samples per pass)
     // score constants (fp64)
     double c_all;           // -dy*log(sqrt(2pi)*sd) - dx*log(sqrt(2pi)) - dx*ct(df, scale)
     double inv_2sd2;        // 1 / (2 sd^2)
@@ -407,27 +491,32 @@ struct Carve {
     int x0, act, scr, yb, xh, total;
 };
 
-__host__ __device__ inline Carve carve_for(int hid, int k0, int in_dim, int out_dim) {
+__host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim) {
     Carve c;
     int off = 0;
-    c.x0 = off; off += k0 * 64 * 4;
-    int act_bytes = hid * 64 * 4;
-    const int part_bytes = 4 * out_dim * 64 * 4;
+    c.x0 = off; off += k0 * ms * 4;
+    int act_bytes = hid * ms * 4;
+    const int part_bytes = 4 * out_dim * ms * 4;
     if (part_bytes > act_bytes) act_bytes = part_bytes;
     c.act = off; off += act_bytes;
-    c.scr = off; off += 4 * 64 * 8;
+    c.scr = off; off += NTHREADS * 8;
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
     c.total = off;
     return c;
 }
 
-template <int HID, bool GIVEN>
-__global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
+// NST = 2: one workgroup per CU, 64 samples per pass, 512 registers per wave.
+// NST = 1: two workgroups per CU, 32 samples per pass each, 256 registers per wave: the two workgroups
+//          drift out of phase, so one's epilogues / barriers / scoring hide behind the other's MFMAs.
+template <int HID, int NST, bool GIVEN>
+__global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArgs a) {
+    constexpr int MS = 32 * NST;          // samples per pass
+    constexpr int NP = NTHREADS / MS;     // threads per sample in the scoring phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MlpArgs& m = a.g;
     const int dx = m.in_dim, dy = m.out_dim;
-    const Carve cv = carve_for(HID, m.k0, dx, dy);
+    const Carve cv = carve_for(HID, MS, m.k0, dx, dy);
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     double* scr = (double*)(smem + cv.scr);
@@ -438,76 +527,85 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int s = lane, p = wave;   // scoring role: sample slot s, dimension phase p
+    const int s = tid % MS, p = tid / MS;   // scoring role: sample slot s, dimension phase p
 
     // zero the padded rows of the x0 image once: rows >= dx are never written again
-    for (int i = tid; i < m.k0 * 16; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef RT_STAMPS
     Stamps st;
     for (int i = 0; i < 8; ++i) st.acc[i] = 0;
     st.t = __builtin_amdgcn_s_memtime();
 #endif
-    for (int64_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+    // contiguous block of work units per workgroup: every workgroup gets the same mix of chunk sizes
+    const int64_t u_lo = a.n_units * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t u_hi = a.n_units * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    for (int64_t unit = u_lo; unit < u_hi; ++unit) {
         const int64_t n = unit / a.nchunks;
         const int c = (int)(unit - n * a.nchunks);
-        const int64_t s_begin = (int64_t)c * a.chunk;
-        const int64_t s_end = (s_begin + a.chunk < a.S) ? s_begin + a.chunk : a.S;
+        // chunk c = passes [c*P/nchunks, (c+1)*P/nchunks): sizes differ by at most one pass
+        const int64_t s_begin = (a.passes * c / a.nchunks) * MS;
+        const int64_t s_hi = (a.passes * (c + 1) / a.nchunks) * MS;
+        const int64_t s_end = (s_hi < a.S) ? s_hi : a.S;
         __syncthreads();   // previous unit's readers of yb / xh are done
         for (int d = tid; d < dy; d += NTHREADS) yb[d] = a.y[n * dy + d];
         for (int d = tid; d < dx; d += NTHREADS) xh[d] = a.xhat[n * dx + d];
         __syncthreads();
 
-        double run_m = -INFINITY, run_s = 0.0;   // online log-sum-exp state (wave 0 lanes)
+        double run_m = -INFINITY, run_s = 0.0;   // online log-sum-exp state (threads < MS)
 
         for (int64_t sb = s_begin; sb < s_end; sb += MS) {
             const int64_t si = sb + s;           // this thread's sample index
+            ST(7)
             // ---- A. proposal samples -> x0 image --------------------------------------------------
             if (GIVEN) {
                 if (si < s_end) {
                     const double* src = a.xs + ((size_t)n * a.S + si) * dx;
-                    for (int d = p; d < dx; d += 4)
-                        *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = (float)src[d];
+                    for (int d = p; d < dx; d += NP)
+                        *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = (float)src[d];
                 } else {
-                    for (int d = p; d < dx; d += 4)
-                        *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = 0.0f;
+                    for (int d = p; d < dx; d += NP)
+                        *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = 0.0f;
                 }
-            } else if (wave == 0) {
+            } else if (tid < MS) {
                 draw_sample(a.sa, (uint64_t)(a.y_index_base + n), (uint32_t)si, xh, dx,
                             [&](int d, float v) {
-                                *(float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v;
+                                *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v;
                             });
             }
             __syncthreads();
             ST(0)
             // ---- B. G forward ---------------------------------------------------------------------
-            mlp_core<HID>(m, x0, act, wave, lane ST_ARG);
-            // ---- C. score: thread (s, p) handles dims d = p, p+4, ... ------------------------------
+            mlp_core<HID, NST>(m, x0, act, wave, lane ST_ARG);
+            // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
             double se = 0.0;
-            for (int d = p; d < dy; d += 4) {
-                const double diff = yb[d] - (double)mlp_out(m, part, d, s);
+            for (int d = p; d < dy; d += NP) {
+                const double diff = yb[d] - (double)mlp_out<MS>(m, part, d, s);
                 se += diff * diff;
             }
             double lw = 0.0;
-            for (int d = p; d < dx; d += 4) {
+            for (int d = p; d < dx; d += NP) {
                 double x;
                 if (GIVEN) x = (si < s_end) ? a.xs[((size_t)n * a.S + si) * dx + d] : 0.0;
-                else x = (double)*(const float*)(x0 + act_off(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
+                else x = (double)*(const float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
                 const double u = ((double)xh[d] - x) * a.inv_scale;
                 lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
             }
-            scr[p * 64 + s] = lw - se * a.inv_2sd2;
+            scr[p * MS + s] = lw - se * a.inv_2sd2;
             __syncthreads();
-            // ---- D. online log-sum-exp (wave 0) ----------------------------------------------------
-            if (wave == 0) {
-                const double v = a.c_all + (((scr[s] + scr[64 + s]) + scr[128 + s]) + scr[192 + s]);
+            // ---- D. online log-sum-exp (one thread per sample) -------------------------------------
+            if (tid < MS) {
+                double acc = scr[s];
+#pragma unroll
+                for (int q = 1; q < NP; ++q) acc += scr[q * MS + s];
+                const double v = a.c_all + acc;
                 if (si < s_end && v > -INFINITY && v < INFINITY) {
                     if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
                     else run_s += exp(v - run_m);
                 }
             }
         }
-        if (wave == 0) {
+        if (wave == 0) {   // threads >= MS carry (-inf, 0)
             double M = run_m;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
@@ -543,29 +641,30 @@ __global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks
 template <int HID>
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, const float* in, int64_t N,
                                                            float* out) {
+    constexpr int MS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Carve cv = carve_for(HID, m.k0, m.in_dim, m.out_dim);
+    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim);
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     const float* part = (const float*)act;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    for (int i = tid; i < m.k0 * 16; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t npass = (N + MS - 1) / MS;
     for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
         const int64_t row = ps * MS + lane;
         __syncthreads();
         for (int d = wave; d < m.in_dim; d += 4)
-            *(float*)(x0 + act_off(d >> 3, lane, (d >> 2) & 1) + 4 * (d & 3)) =
+            *(float*)(x0 + act_off<MS>(d >> 3, lane, (d >> 2) & 1) + 4 * (d & 3)) =
                 (row < N) ? in[row * m.in_dim + d] : 0.0f;
         __syncthreads();
 #ifdef RT_STAMPS
         Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
 #endif
-        mlp_core<HID>(m, x0, act, wave, lane ST_ARG);
+        mlp_core<HID, 2>(m, x0, act, wave, lane ST_ARG);
         if (row < N)
-            for (int d = wave; d < m.out_dim; d += 4) out[row * m.out_dim + d] = mlp_out(m, part, d, lane);
+            for (int d = wave; d < m.out_dim; d += 4) out[row * m.out_dim + d] = mlp_out<MS>(m, part, d, lane);
     }
 }
 
@@ -602,6 +701,8 @@ struct HostMlp {
 struct rt_ctx {
     int device = 0;
     int cu_count = 0;
+    int nst = 2;   // sample tiles per wave: 2 = one 64-sample workgroup per CU.  (1 = two 32-sample workgroups per
+                   // CU was measured at 68 % of peak vs 85 %: it doubles the weight stream per MFMA)
     hipStream_t stream = nullptr;
     HostMlp mlp[2];
     DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
@@ -661,16 +762,16 @@ void free_mlp(HostMlp& m) {
     m.set = false;
 }
 
-template <int HID>
+template <int HID, int NST>
 int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
     if (given) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, true>,
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((is_fused_kernel<HID, true>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
+        hipLaunchKernelGGL((is_fused_kernel<HID, NST, true>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
     } else {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, false>,
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((is_fused_kernel<HID, false>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
+        hipLaunchKernelGGL((is_fused_kernel<HID, NST, false>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
     }
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
@@ -712,15 +813,16 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     if (rc) return rc;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     // work units: (query point, chunk of samples); aim for >= 128 units per CU-resident workgroup
-    const int grid_max = ctx->cu_count;
+    const int nst = ctx->nst;
+    const int MS = 32 * nst;
+    const int grid_max = ctx->cu_count * (nst == 1 ? 2 : 1);
     const int64_t passes = (S + MS - 1) / MS;
     int64_t want = (128ll * grid_max + N - 1) / N;
     if (want < 1) want = 1;
     if (want > passes) want = passes;
-    const int64_t ppc = (passes + want - 1) / want;
-    const int64_t nchunks = (passes + ppc - 1) / ppc;
+    const int64_t nchunks = want;
     a.nchunks = (int)nchunks;
-    a.chunk = (int)(ppc * MS);
+    a.passes = passes;
     a.n_units = N * nchunks;
     a.N = N; a.S = S; a.y_index_base = y_index_base;
     a.y = y; a.xhat = xhat; a.xs = xs;
@@ -735,7 +837,7 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     a.inv_df = 1.0 / df;
     a.half_dfp1 = 0.5 * (df + 1.0);
 
-    const Carve cv = carve_for(G.hid, G.args.k0, dx, dy);
+    const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy);
     const int grid = (int)((a.n_units < grid_max) ? a.n_units : grid_max);
     if (ctx->events_used == ctx->events.size()) {
         hipEvent_t e0, e1;
@@ -745,10 +847,11 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     }
     auto& ev = ctx->events[ctx->events_used];
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
-    switch (G.hid) {
-        case 128: rc = launch_is<128>(ctx, a, xs != nullptr, grid, cv.total); break;
-        case 256: rc = launch_is<256>(ctx, a, xs != nullptr, grid, cv.total); break;
-        case 512: rc = launch_is<512>(ctx, a, xs != nullptr, grid, cv.total); break;
+    const bool given = xs != nullptr;
+    switch (G.hid * 10 + nst) {
+        case 1282: rc = launch_is<128, 2>(ctx, a, given, grid, cv.total); break;
+        case 2562: rc = launch_is<256, 2>(ctx, a, given, grid, cv.total); break;
+        case 5122: rc = launch_is<512, 2>(ctx, a, given, grid, cv.total); break;
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
     if (rc) return rc;
@@ -769,8 +872,8 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
     if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
     if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
     if (N == 0) return RT_OK;
-    const Carve cv = carve_for(M.hid, M.args.k0, M.args.in_dim, M.args.out_dim);
-    const int64_t npass = (N + MS - 1) / MS;
+    const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const int64_t npass = (N + 63) / 64;
     const int64_t gmax = (int64_t)ctx->cu_count * 2;
     const int grid = (int)(npass < gmax ? npass : gmax);
     switch (M.hid) {
@@ -837,7 +940,7 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
         return fail(ctx, RT_EUNSUPPORTED, "hidden width must be 128, 256 or 512");
     if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 128");
     if (dims[n_layers] > MAX_OUT) return fail(ctx, RT_EUNSUPPORTED, "output dim > 128");
-    if (carve_for(hid, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
+    if (carve_for(hid, 64, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
         return fail(ctx, RT_EUNSUPPORTED, "input dim too large for this hidden width (LDS budget of 160 KiB)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
