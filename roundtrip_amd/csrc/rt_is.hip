@@ -29,6 +29,7 @@
 
 #include "../../include/rt_is.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -83,16 +84,20 @@ __device__ __forceinline__ int act_off(int kg, int s, int hh) {
 // MFMA 32x32x2 operand maps (cdna_hip_programming.md §3): lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // here lane half h at step e handles k = 8kg + 4h + e (any k order is a valid sum).
 // ----------------------------------------------------------------------------------------------
-template <int NFT, int NST>
+// FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
+// accumulator clearing (128 v_accvgpr_write per layer otherwise).
+template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
                                            const f32x4 (&b)[NST]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
             for (int st = 0; st < NST; ++st)
-                acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][e], b[st][e], acc[ft][st], 0, 0, 0);
+                acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][e], b[st][e],
+                                                                   (FIRST && e == 0) ? zero : acc[ft][st], 0, 0, 0);
 }
 
 // acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
@@ -100,6 +105,40 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
 //          between feature tiles = 64 f32x4
 //   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 64*NST*16 B,
 //          sample tile stride 1024 B
+#ifndef RT_BUFLOAD
+#define RT_BUFLOAD 1   // 1: weights by buffer_load (SGPR descriptor + scalar k-group offset, no per-lane address math)
+#endif
+// Source of one wave's packed weights for a layer.
+struct WSrc {
+#if RT_BUFLOAD
+    __amdgpu_buffer_rsrc_t r;
+    int voff;            // lane * 16
+#else
+    const f32x4* p;      // base + lane
+#endif
+};
+// base must be wave-uniform (kernel argument + wave index from readfirstlane).
+__device__ __forceinline__ WSrc make_wsrc(const float* base, int lane) {
+    WSrc w;
+#if RT_BUFLOAD
+    w.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    w.voff = lane * 16;
+#else
+    w.p = (const f32x4*)base + lane;
+#endif
+    return w;
+}
+// A operands of (k-group kg, feature tile ft); wstride = f32x4 elements between k-groups.
+__device__ __forceinline__ f32x4 wload(const WSrc& w, int kg, int wstride, int ft) {
+#if RT_BUFLOAD
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, w.voff + ft * 1024, kg * wstride * 16, 0);
+    return __builtin_bit_cast(f32x4, v);
+#else
+    return w.p[(size_t)kg * wstride + ft * 64];
+#endif
+}
+
 #ifndef RT_SCHED
 #define RT_SCHED 0   // placement of the K loop's memory instructions among the MFMAs (see pipe_stage)
 #endif
@@ -107,13 +146,12 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
 #define RT_ABL 0   // diagnostic ablations (never set in the shipped build): 1 = no weight loads, 2 = no LDS reads in the K loop
 #endif
 template <int NFT, int NST, int ABL = 0>
-__device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], const f32x4* __restrict__ wl,
+__device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], const WSrc& wl,
                                            int wstride, const char* bl, int kg) {
-    const f32x4* w = wl + (size_t)kg * wstride;
     const char* l = bl + kg * (1024 * NST);
     if (!(ABL & 1)) {
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) a[ft] = w[ft * 64];
+        for (int ft = 0; ft < NFT; ++ft) a[ft] = wload(wl, kg, wstride, ft);
     } else {
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) asm volatile("" : "+v"(a[ft]));
@@ -127,11 +165,13 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], con
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
 template <int NFT, int NST>
-__device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const f32x4* __restrict__ wl,
+__device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const WSrc& wl,
                                                  int ftt, int nkg, const char* bl) {
     f32x4 a[NFT], b[NST];
+    load_group<NFT, NST>(a, b, wl, ftt * 64, bl, 0);
+    mfma_group<NFT, NST, true>(acc, a, b);
 #pragma unroll 1
-    for (int kg = 0; kg < nkg; ++kg) {
+    for (int kg = 1; kg < nkg; ++kg) {
         load_group<NFT, NST>(a, b, wl, ftt * 64, bl, kg);
         mfma_group<NFT, NST>(acc, a, b);
     }
@@ -141,12 +181,12 @@ __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const 
 // of the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
 // the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
 // behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
-template <int NFT, int NST>
+template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
-                                           const f32x4* __restrict__ wl, int wstride, const char* bl, int kgn) {
+                                           const WSrc& wl, int wstride, const char* bl, int kgn) {
     load_group<NFT, NST, RT_ABL>(an, bn, wl, wstride, bl, kgn);
-    mfma_group<NFT, NST>(acc, ac, bc);
+    mfma_group<NFT, NST, FIRST>(acc, ac, bc);
     constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
 #if RT_SCHED == 0
 #pragma unroll
@@ -202,12 +242,12 @@ __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[
 // activations, so this is issued BEFORE the previous layer's epilogue and barriers and lands behind them.
 template <int NFT>
 __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f32x4 (&a2)[NFT],
-                                           const f32x4* __restrict__ wl, int wstride) {
+                                           const WSrc& wl, int wstride) {
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
-        a0[ft] = wl[ft * 64];
-        a1[ft] = wl[(size_t)wstride + ft * 64];
-        a2[ft] = wl[(size_t)2 * wstride + ft * 64];
+        a0[ft] = wload(wl, 0, wstride, ft);
+        a1[ft] = wload(wl, 1, wstride, ft);
+        a2[ft] = wload(wl, 2, wstride, ft);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -217,7 +257,7 @@ __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f
 // a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
 template <int NFT, int NST>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
-                                          f32x4 (&a2)[NFT], const f32x4* __restrict__ wl,
+                                          f32x4 (&a2)[NFT], const WSrc& wl,
                                           int ftt, int nkg, const char* bl) {
     f32x4 a3[NFT], b0[NST], b1[NST], b2[NST], b3[NST];
     const int wstride = ftt * 64;
@@ -230,8 +270,13 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
     }
     if (RT_ABL) load_group<NFT, NST>(a3, b3, wl, wstride, bl, 3);
     __builtin_amdgcn_sched_barrier(0);
+    // first four k-groups peeled: their first MFMAs start the accumulators from the constant 0
+    pipe_stage<NFT, NST, true>(acc, a3, b3, a0, b0, wl, wstride, bl, 3);
+    pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(4, lastg));
+    pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(5, lastg));
+    pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(6, lastg));
 #pragma unroll 1
-    for (int kg = 0; kg < nkg; kg += 4) {
+    for (int kg = 4; kg < nkg; kg += 4) {
         pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
         pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
         pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
@@ -270,17 +315,17 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], const f32x4 (
             for (int st = 0; st < NST; ++st) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[ft][st][4 * q + e] + bv[ft][q][e];
-                    v[e] = fmaxf(t, alpha * t);
+                for (int e = 0; e < 4; e += 2) {
+                    // two lanes' worth per instruction: v_pk_add_f32 / v_pk_mul_f32 (same IEEE results)
+                    const f32x2 t = f32x2{acc[ft][st][4 * q + e], acc[ft][st][4 * q + e + 1]} +
+                                    f32x2{bv[ft][q][e], bv[ft][q][e + 1]};
+                    const f32x2 u = t * f32x2{alpha, alpha};
+                    v[e] = fmaxf(t[0], u[0]);
+                    v[e + 1] = fmaxf(t[1], u[1]);
                 }
                 *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 * st + j, h)) = v;
             }
         }
-#pragma unroll
-        for (int st = 0; st < NST; ++st)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
     }
 }
 
@@ -292,13 +337,7 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc[NT][NST];
-#pragma unroll
-    for (int ft = 0; ft < NT; ++ft)
-#pragma unroll
-        for (int st = 0; st < NST; ++st)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
-    const f32x4* wl = (const f32x4*)m.wp[m.n_layers - 1] + (size_t)(wave * kq) * NT * 64 + lane;
+    const WSrc wl = make_wsrc(m.wp[m.n_layers - 1] + (size_t)(wave * kq) * NT * 256, lane);
     f32x4 a0[NT], a1[NT], a2[NT];
     prefetch_a<NT>(a0, a1, a2, wl, NT * 64);
     gemm_tile<NT, NST>(acc, a0, a1, a2, wl, NT, kq, act + act_off<MS>(wave * kq, j, h));
@@ -327,22 +366,15 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc[NFT][NST];
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft)
-#pragma unroll
-        for (int st = 0; st < NST; ++st)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ft][st][e] = 0.0f;
-
     f32x4 bv[NFT][4];
     load_bias<NFT>(bv, m.bp[0], wave, lane);
-    gemm_tile_simple<NFT, NST>(acc, (const f32x4*)m.wp[0] + (wave * NFT) * 64 + lane, FTT, m.k0 >> 3,
+    gemm_tile_simple<NFT, NST>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
                                x0 + act_off<MS>(0, j, h));
     ST(1)
     const int nhid = m.n_layers - 1;
     f32x4 a0[NFT], a1[NFT], a2[NFT];
     for (int l = 0; l < nhid; ++l) {
-        const f32x4* wnext = (const f32x4*)m.wp[l + 1] + (wave * NFT) * 64 + lane;
+        const WSrc wnext = make_wsrc(m.wp[l + 1] + (wave * NFT) * 256, lane);
         if (l + 1 < nhid) prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
