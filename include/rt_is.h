@@ -39,6 +39,7 @@ extern "C" {
 #define RT_MLP_H 1           /* encoder    H: y (dy) -> x (dx)  : h_net / e_net, main_density_est.py:448 */
 
 #define RT_MAX_LAYERS 24
+#define RT_MAX_SD 8          /* sd_y values one rt_is_estimate_multi call can score */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -96,6 +97,15 @@ int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);
 int rt_is_estimate(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
                    int64_t S, double sd_y, double scale, double df, uint64_t seed, int log_flag,
                    double* out);
+
+/* The same estimate for n_sd (<= RT_MAX_SD) values of sd_y at once: out is n_sd x N (row k = sd_y[k]).
+ * Replaces the inner loop of model_selection (main_density_est.py:207-219), which calls the estimator once
+ * per (sd, scale) pair after reseeding with 0 each time: for a fixed scale the draws — and therefore G(x_i) —
+ * are the same for every sd, so one sampler + G pass serves all of them (3x fewer flops for its sd_list).
+ * Row k is bit-identical to rt_is_estimate(..., sd_y[k], ...). */
+int rt_is_estimate_multi(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                         int64_t S, int n_sd, const double* sd_y, double scale, double df, uint64_t seed,
+                         int log_flag, double* out);
 
 /* Same, with the proposal samples supplied by the caller instead of drawn on the GPU (parity mode):
  *   x_samples  N x S x dx float64 — what sample_from_qx (:310-318) returned for each query point.

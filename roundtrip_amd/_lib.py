@@ -17,7 +17,7 @@ RT_MLP_H = 1
 # every symbol include/rt_is.h declares (tests check the library exports each one)
 SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_encode",
-    "rt_is_estimate", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
+    "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
 )
 
@@ -54,6 +54,7 @@ def load():
     lib.rt_mlp_forward.argtypes = [vp, C.c_int, vp, i64, vp]
     lib.rt_encode.argtypes = [vp, vp, i64, vp]
     lib.rt_is_estimate.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, C.c_int, vp]
+    lib.rt_is_estimate_multi.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, dbl, dbl, C.c_uint64, C.c_int, vp]
     lib.rt_is_estimate_given_samples.argtypes = [vp, vp, vp, vp, i64, i64, dbl, dbl, dbl, C.c_int, vp]
     lib.rt_draw_samples.argtypes = [vp, vp, i64, i64, i64, dbl, dbl, C.c_uint64, vp]
     lib.rt_is_estimate_dev.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, C.c_int, vp]
@@ -143,6 +144,23 @@ class Engine(object):
         self._chk(self._lib.rt_is_estimate(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
                                            int(sample_size), float(sd_y), float(scale), float(df),
                                            int(seed), int(bool(log)), out.ctypes.data))
+        return out
+
+    def is_estimate_multi(self, y, xhat, sample_size, sd_ys, scale, df=1.0, seed=0, log=True, y_index_base=0):
+        """One sampler + G pass scored for every sd in sd_ys; returns (len(sd_ys), N)."""
+        dx, dy = self._g_dims()
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != dy:
+            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
+        N = y.shape[0]
+        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
+        if xhat.shape != (N, dx):
+            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
+        out = np.empty((sds.size, N), dtype=np.float64)
+        self._chk(self._lib.rt_is_estimate_multi(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
+                                                 int(sample_size), int(sds.size), sds.ctypes.data, float(scale),
+                                                 float(df), int(seed), int(bool(log)), out.ctypes.data))
         return out
 
     def is_estimate_given_samples(self, y, xhat, x_samples, sd_y, scale, df=1.0, log=True):

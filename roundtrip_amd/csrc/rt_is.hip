@@ -506,21 +506,22 @@ struct IsArgs {
     const double* y;        // N x dy
     const float* xhat;      // N x dx
     const double* xs;       // given samples N x S x dx, or nullptr
-    double* partial;        // n_units x 2 : (max, sum exp(v - max))
+    double* partial;        // n_units x n_sd x 2 : (max, sum exp(v - max))
     int64_t N, S, y_index_base;
     int64_t n_units;
     int nchunks;            // chunks per query point
     int64_t passes;         // ceil(S / samples per pass)
     // score constants (fp64)
-    double c_all;           // -dy*log(sqrt(2pi)*sd) - dx*log(sqrt(2pi)) - dx*ct(df, scale)
-    double inv_2sd2;        // 1 / (2 sd^2)
+    int n_sd;               // number of sd_y values scored on the same draws and the same G pass (1..RT_MAX_SD)
+    double c_all[RT_MAX_SD];     // -dy*log(sqrt(2pi)*sd) - dx*log(sqrt(2pi)) - dx*ct(df, scale)
+    double inv_2sd2[RT_MAX_SD];  // 1 / (2 sd^2)
     double inv_scale;
     double inv_df;
     double half_dfp1;       // (df+1)/2
 };
 
 struct Carve {
-    int x0, act, scr, yb, xh, total;
+    int x0, act, scr, lse, yb, xh, total;
 };
 
 __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim) {
@@ -531,7 +532,8 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     const int part_bytes = 4 * out_dim * ms * 4;
     if (part_bytes > act_bytes) act_bytes = part_bytes;
     c.act = off; off += act_bytes;
-    c.scr = off; off += NTHREADS * 8;
+    c.scr = off; off += 2 * NTHREADS * 8;            // per (phase, sample): squared error, log weight
+    c.lse = off; off += 2 * RT_MAX_SD * ms * 8;      // per (sd, sample slot): running max, running sum
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
     c.total = off;
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArg
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     double* scr = (double*)(smem + cv.scr);
+    double* lse = (double*)(smem + cv.lse);
     double* yb = (double*)(smem + cv.yb);
     float* xh = (float*)(smem + cv.xh);
     const float* part = (const float*)act;
@@ -584,7 +587,9 @@ __global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArg
         for (int d = tid; d < dx; d += NTHREADS) xh[d] = a.xhat[n * dx + d];
         __syncthreads();
 
-        double run_m = -INFINITY, run_s = 0.0;   // online log-sum-exp state (threads < MS)
+        // online log-sum-exp state per (sd, sample slot) lives in LDS: lse[(2k)*MS + s] = max, [(2k+1)*MS + s] = sum
+        if (tid < MS)
+            for (int k = 0; k < a.n_sd; ++k) { lse[(2 * k) * MS + s] = -INFINITY; lse[(2 * k + 1) * MS + s] = 0.0; }
 
         for (int64_t sb = s_begin; sb < s_end; sb += MS) {
             const int64_t si = sb + s;           // this thread's sample index
@@ -623,28 +628,41 @@ __global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArg
                 const double u = ((double)xh[d] - x) * a.inv_scale;
                 lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
             }
-            scr[p * MS + s] = lw - se * a.inv_2sd2;
+            scr[p * MS + s] = se;
+            scr[NTHREADS + p * MS + s] = lw;
             __syncthreads();
-            // ---- D. online log-sum-exp (one thread per sample) -------------------------------------
-            if (tid < MS) {
-                double acc = scr[s];
+            // ---- D. online log-sum-exp (one thread per sample; one state per sd_y) ------------------
+            if (tid < MS && si < s_end) {
+                double se_t = scr[s], lw_t = scr[NTHREADS + s];
 #pragma unroll
-                for (int q = 1; q < NP; ++q) acc += scr[q * MS + s];
-                const double v = a.c_all + acc;
-                if (si < s_end && v > -INFINITY && v < INFINITY) {
-                    if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
-                    else run_s += exp(v - run_m);
+                for (int q = 1; q < NP; ++q) { se_t += scr[q * MS + s]; lw_t += scr[NTHREADS + q * MS + s]; }
+                for (int k = 0; k < a.n_sd; ++k) {
+                    const double v = a.c_all[k] + (lw_t - se_t * a.inv_2sd2[k]);
+                    if (v > -INFINITY && v < INFINITY) {
+                        double run_m = lse[(2 * k) * MS + s], run_s = lse[(2 * k + 1) * MS + s];
+                        if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
+                        else run_s += exp(v - run_m);
+                        lse[(2 * k) * MS + s] = run_m;
+                        lse[(2 * k + 1) * MS + s] = run_s;
+                    }
                 }
             }
         }
-        if (wave == 0) {   // threads >= MS carry (-inf, 0)
-            double M = run_m;
+        if (wave == 0) {
+            for (int k = 0; k < a.n_sd; ++k) {
+                const double run_m = (lane < MS) ? lse[(2 * k) * MS + lane] : -INFINITY;
+                const double run_s = (lane < MS) ? lse[(2 * k + 1) * MS + lane] : 0.0;
+                double M = run_m;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
-            double t = (run_m > -INFINITY) ? run_s * exp(run_m - M) : 0.0;
+                for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
+                double t = (run_m > -INFINITY) ? run_s * exp(run_m - M) : 0.0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-            if (lane == 0) { a.partial[2 * unit] = M; a.partial[2 * unit + 1] = t; }
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                if (lane == 0) {
+                    a.partial[2 * (unit * a.n_sd + k)] = M;
+                    a.partial[2 * (unit * a.n_sd + k) + 1] = t;
+                }
+            }
         }
     }
 #ifdef RT_STAMPS
@@ -653,18 +671,22 @@ __global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArg
 #endif
 }
 
-__global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, double logS,
+// out[k*N + n] for sd index k: merges the chunks of query point n.
+__global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, int n_sd, double logS,
                                    int log_flag, double* out) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const double* p = partial + 2 * n * nchunks;
-    double M = -INFINITY;
-    for (int c = 0; c < nchunks; ++c) M = fmax(M, p[2 * c]);
-    double t = 0.0;
-    for (int c = 0; c < nchunks; ++c)
-        if (p[2 * c] > -INFINITY) t += p[2 * c + 1] * exp(p[2 * c] - M);
-    const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
-    out[n] = log_flag ? lp : exp(lp);
+    for (int k = 0; k < n_sd; ++k) {
+        const double* p = partial + 2 * (n * nchunks * n_sd + k);   // chunk stride: 2*n_sd doubles
+        const int cs = 2 * n_sd;
+        double M = -INFINITY;
+        for (int c = 0; c < nchunks; ++c) M = fmax(M, p[c * cs]);
+        double t = 0.0;
+        for (int c = 0; c < nchunks; ++c)
+            if (p[c * cs] > -INFINITY) t += p[c * cs + 1] * exp(p[c * cs] - M);
+        const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
+        out[(int64_t)k * N + n] = log_flag ? lp : exp(lp);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -831,12 +853,14 @@ int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArg
 
 // Enqueues the fused kernel + finalize.  All pointers are device pointers.
 int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
-               int64_t y_index_base, int64_t S, double sd_y, double scale, double df, uint64_t seed,
-               int log_flag, double* out) {
+               int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
+               uint64_t seed, int log_flag, double* out) {
     HostMlp& G = ctx->mlp[RT_MLP_G];
     if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
     if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
-    if (!(sd_y > 0.0) || !isfinite(sd_y)) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
+    if (n_sd < 1 || n_sd > RT_MAX_SD || !sd_ys) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
+    for (int k = 0; k < n_sd; ++k)
+        if (!(sd_ys[k] > 0.0) || !isfinite(sd_ys[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
     if (N == 0) return RT_OK;
     IsArgs a;
     memset(&a, 0, sizeof(a));
@@ -858,13 +882,17 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     a.n_units = N * nchunks;
     a.N = N; a.S = S; a.y_index_base = y_index_base;
     a.y = y; a.xhat = xhat; a.xs = xs;
-    rc = ensure(ctx, ctx->b_partial, (size_t)a.n_units * 2 * sizeof(double));
+    a.n_sd = n_sd;
+    rc = ensure(ctx, ctx->b_partial, (size_t)a.n_units * n_sd * 2 * sizeof(double));
     if (rc) return rc;
     a.partial = (double*)ctx->b_partial.p;
     const double PI = 3.14159265358979323846;
     const double ct = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * PI) - log(scale);
-    a.c_all = -(double)dy * log(sqrt(2.0 * PI) * sd_y) - (double)dx * log(sqrt(2.0 * PI)) - (double)dx * ct;
-    a.inv_2sd2 = 1.0 / (2.0 * sd_y * sd_y);
+    for (int k = 0; k < n_sd; ++k) {
+        const double sd_y = sd_ys[k];
+        a.c_all[k] = -(double)dy * log(sqrt(2.0 * PI) * sd_y) - (double)dx * log(sqrt(2.0 * PI)) - (double)dx * ct;
+        a.inv_2sd2[k] = 1.0 / (2.0 * sd_y * sd_y);
+    }
     a.inv_scale = 1.0 / scale;
     a.inv_df = 1.0 / df;
     a.half_dfp1 = 0.5 * (df + 1.0);
@@ -893,7 +921,7 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     ctx->evals_acc += (uint64_t)N * (uint64_t)S;
     const int fb = 256;
     hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + fb - 1) / fb)), dim3(fb), 0, ctx->stream,
-                       (const double*)a.partial, N, a.nchunks, log((double)S), log_flag, out);
+                       (const double*)a.partial, N, a.nchunks, n_sd, log((double)S), log_flag, out);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1046,21 +1074,22 @@ int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat) {
 }
 
 static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
-                   int64_t y_index_base, int64_t S, double sd_y, double scale, double df, uint64_t seed,
-                   int log_flag, double* out, bool given) {
+                   int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
+                   uint64_t seed, int log_flag, double* out, bool given) {
     if (!ctx) return RT_EINVAL;
     HostMlp& G = ctx->mlp[RT_MLP_G];
     if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
     if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
     if (N == 0) return RT_OK;
-    if (!y || !xhat || !out || (given && !xs)) return fail(ctx, RT_EINVAL, "NULL argument");
+    if (!y || !xhat || !out || (given && !xs) || !sd_ys) return fail(ctx, RT_EINVAL, "NULL argument");
     if (S <= 0) return fail(ctx, RT_EINVAL, "S must be positive");
+    if (n_sd < 1 || n_sd > RT_MAX_SD) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     const size_t yb = (size_t)N * dy * sizeof(double), xb = (size_t)N * dx * sizeof(float);
     int rc = ensure(ctx, ctx->b_y, yb); if (rc) return rc;
     rc = ensure(ctx, ctx->b_xhat, xb); if (rc) return rc;
-    rc = ensure(ctx, ctx->b_out, (size_t)N * sizeof(double)); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_out, (size_t)N * n_sd * sizeof(double)); if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_y.p, y, yb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_xhat.p, xhat, xb, hipMemcpyHostToDevice, ctx->stream));
     const double* xs_dev = nullptr;
@@ -1071,9 +1100,9 @@ static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double
         xs_dev = (const double*)ctx->b_xs.p;
     }
     rc = is_enqueue(ctx, (const double*)ctx->b_y.p, (const float*)ctx->b_xhat.p, xs_dev, N, y_index_base,
-                    S, sd_y, scale, df, seed, log_flag, (double*)ctx->b_out.p);
+                    S, n_sd, sd_ys, scale, df, seed, log_flag, (double*)ctx->b_out.p);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, (size_t)N * n_sd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1081,13 +1110,19 @@ static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double
 int rt_is_estimate(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
                    int64_t S, double sd_y, double scale, double df, uint64_t seed, int log_flag,
                    double* out) {
-    return is_host(ctx, y, xhat, nullptr, N, y_index_base, S, sd_y, scale, df, seed, log_flag, out, false);
+    return is_host(ctx, y, xhat, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out, false);
+}
+
+int rt_is_estimate_multi(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                         int64_t S, int n_sd, const double* sd_y, double scale, double df, uint64_t seed,
+                         int log_flag, double* out) {
+    return is_host(ctx, y, xhat, nullptr, N, y_index_base, S, n_sd, sd_y, scale, df, seed, log_flag, out, false);
 }
 
 int rt_is_estimate_given_samples(rt_ctx* ctx, const double* y, const float* xhat, const double* x_samples,
                                  int64_t N, int64_t S, double sd_y, double scale, double df, int log_flag,
                                  double* out) {
-    return is_host(ctx, y, xhat, x_samples, N, 0, S, sd_y, scale, df, 0, log_flag, out, true);
+    return is_host(ctx, y, xhat, x_samples, N, 0, S, 1, &sd_y, scale, df, 0, log_flag, out, true);
 }
 
 int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
@@ -1096,7 +1131,7 @@ int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, 
     if (!ctx) return RT_EINVAL;
     if (N > 0 && (!y_dev || !xhat_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, sd_y, scale, df, seed, log_flag, out_dev);
+    return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev);
 }
 
 int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,

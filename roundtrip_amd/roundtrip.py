@@ -83,6 +83,30 @@ class _IsModelBase(object):
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
 
+    def _estimate_is_multi(self, points, sds, scale, sample_size, df, log):
+        """(len(sds), N): the estimate for several sd values from ONE sampler + G pass (same draws, as in the
+        reference, which reseeds with 0 before every call)."""
+        g_net = self._nets()[0][1]
+        points = np.asarray(points)
+        assert points.ndim == 2 and points.shape[-1] == g_net.output_dim
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        sds = [float(v) for v in sds]
+        self._sync_weights()
+        eng = self.engine
+        if points.shape[0] == 0:
+            return np.zeros((len(sds), 0), dtype=np.float64)
+        rank, ws = dist.world()
+        if not (self.shard and ws > 1):
+            centres = eng.mlp_forward(_lib.RT_MLP_H, points.astype(np.float32))
+            return eng.is_estimate_multi(points, centres, sample_size, sds, scale, df=df, seed=self.is_seed, log=log)
+        lo, hi = dist.shard_bounds(points.shape[0], ws, rank)
+        local = np.zeros((len(sds), 0))
+        if hi > lo:
+            centres = eng.mlp_forward(_lib.RT_MLP_H, points[lo:hi].astype(np.float32))
+            local = eng.is_estimate_multi(points[lo:hi], centres, sample_size, sds, scale, df=df,
+                                          seed=self.is_seed, log=log, y_index_base=lo)
+        return np.stack([dist.all_gather_blocks(local[k], points.shape[0]) for k in range(len(sds))])
+
 
 class Roundtrip(_IsModelBase):
     """Roundtrip model for density estimation — the importance-sampling path (v2 API)."""
@@ -216,6 +240,38 @@ class RoundtripModel(_IsModelBase):
                 os.makedirs(self.save_dir)
             np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
         return py_est
+
+    def model_selection(self, sample_size=20000):
+        """main_density_est.py:207-219: picks (sd, scale) maximising the mean validation log-likelihood over
+        sd in {.05,.1,.5} x scale in {.005,.01,.1,.5,1}.  The reference runs 15 estimates; here each scale is one
+        sampler + G pass scored for the three sd values (rt_is_estimate_multi), with identical results."""
+        data_y_val = self.y_sampler.X_val
+        sd_list = [0.05, 0.1, 0.5]
+        scale_list = [0.005, 0.01, 0.1, 0.5, 1]
+        mean = {}
+        for scale in scale_list:
+            est = self._estimate_is_multi(data_y_val, sd_list, scale, sample_size, self.df, True)
+            for sd, row in zip(sd_list, est):
+                mean[(sd, scale)] = np.mean(row)
+        records = []
+        for sd in sd_list:
+            for scale in scale_list:
+                records.append([sd, scale, mean[(sd, scale)]])
+        # sort according to the likelihood of validation set
+        records.sort(key=lambda item: item[-1])
+        best_sd, best_scale = records[-1][0], records[-1][1]
+        return best_sd, best_scale
+
+    def likelihood_summary(self, y_points, epoch, sd_y, scale, sample_size=2000, log_file=None, save=False):
+        """The validation / test bookkeeping of train() (main_density_est.py:186-196): mean log-likelihood and its
+        standard error; appends '<epoch>\t<mean>\t<stderr>' to log_file (an open file) when given."""
+        py_est = self.estimate_py_with_IS(y_points, epoch, sd_y=sd_y, scale=scale, sample_size=sample_size,
+                                          log=True, save=save)
+        average_likelihood = np.mean(py_est)
+        sd_likelihood = np.std(py_est) / np.sqrt(len(py_est))
+        if log_file is not None:
+            log_file.write('%d\t%f\t%f\n' % (epoch, average_likelihood, sd_likelihood))
+        return average_likelihood, sd_likelihood
 
     def estimate_px_with_IS(self, x_points, sd_x=0.5, scale=0.5, sample_size=40000, bs=1024, df=1, log=True):
         """v2 spelling on the v1 object (x is the data point there)."""

@@ -70,3 +70,33 @@ def test_v1_model(tmp_path, monkeypatch):
     assert len(os.listdir(m.save_dir)) == 1
     m.estimate_py_with_IS(y, 6, sample_size=64, save=False)
     assert len(os.listdir(m.save_dir)) == 1
+
+
+def test_v1_model_selection_and_likelihood_summary(tmp_path, monkeypatch):
+    """model_selection (main_density_est.py:207-219) and the validation bookkeeping (:186-189)."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(7)
+    g = Generator(2, 2, "g_net", nb_layers=3, nb_units=128, rng=rng)
+    h = Generator(2, 2, "h_net", nb_layers=3, nb_units=128, rng=rng)
+
+    class Sampler(object):
+        X_val = np.random.RandomState(8).standard_normal((40, 2)) * 0.3
+
+    m = RoundtripModel(g, h, None, None, None, Sampler(), "toy", None, 64, 10.0, 10.0, 1, False)
+    S = 500
+    best_sd, best_scale = m.model_selection(sample_size=S)
+    # the reference's way: 15 separate estimates
+    records = []
+    for sd in [0.05, 0.1, 0.5]:
+        for scale in [0.005, 0.01, 0.1, 0.5, 1]:
+            est = m.estimate_py_with_IS(Sampler.X_val, 0, sd_y=sd, scale=scale, sample_size=S, log=True, save=False)
+            records.append([sd, scale, np.mean(est)])
+    records.sort(key=lambda item: item[-1])
+    assert (best_sd, best_scale) == (records[-1][0], records[-1][1])
+    with open("log_val.txt", "a+") as f:
+        mean, se = m.likelihood_summary(Sampler.X_val, 4, best_sd, best_scale, sample_size=S, log_file=f)
+    est = m.estimate_py_with_IS(Sampler.X_val, 4, sd_y=best_sd, scale=best_scale, sample_size=S, save=False)
+    assert mean == np.mean(est) and se == np.std(est) / np.sqrt(len(est))
+    assert open("log_val.txt").read() == "%d\t%f\t%f\n" % (4, mean, se)

@@ -270,3 +270,28 @@ def test_full_size_properties(engine, make_nets):
         want = c_oracle.is_estimate_given_samples(og, grid[i:i + 1], xhat[i:i + 1], xs, 0.1, 0.5, 1.0, True,
                                                   c_oracle.ORDER_KERNEL, 8)
         np.testing.assert_allclose(lg[i], want[0], rtol=1e-12)
+
+
+def test_multi_sd_shares_one_generator_pass(engine, make_nets):
+    """rt_is_estimate_multi (model_selection's inner loop, main_density_est.py:207-219): every row is
+    bit-identical to the single-sd call, in log and linear mode, across chunked and unchunked shapes."""
+    gw, gb, hw, hb = make_nets(3, 6)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    sds = [0.05, 0.1, 0.5]
+    for n, S in ((5, 2000), (700, 130)):
+        y = np.random.RandomState(n).standard_normal((n, 6)) * 0.1
+        xhat = engine.mlp_forward(H, y.astype(np.float32))
+        for log in (True, False):
+            multi = engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=0, log=log)
+            assert multi.shape == (3, n)
+            for k, sd in enumerate(sds):
+                assert np.array_equal(multi[k], engine.is_estimate(y, xhat, S, sd, 0.1, 1.0, seed=0, log=log))
+    engine.reset_counters()
+    engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0)
+    c = engine.counters()
+    assert c["sample_evals"] == 700 * 130 and c["launches"] == 1     # one G pass, not three
+    with pytest.raises(_lib.RtError):
+        engine.is_estimate_multi(y, xhat, S, [0.1] * 9, 0.1)
+    with pytest.raises(_lib.RtError):
+        engine.is_estimate_multi(y, xhat, S, [0.1, -1.0], 0.1)
