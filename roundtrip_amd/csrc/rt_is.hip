@@ -540,11 +540,11 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     return c;
 }
 
-// NST = 2: one workgroup per CU, 64 samples per pass, 512 registers per wave.
-// NST = 1: two workgroups per CU, 32 samples per pass each, 256 registers per wave: the two workgroups
-//          drift out of phase, so one's epilogues / barriers / scoring hide behind the other's MFMAs.
+// One workgroup per CU, up to 512 registers per wave.  NST = 2: 64 samples per pass (hidden width <= 512).
+// NST = 1: 32 samples per pass, used for hidden width 1024, whose 64-sample activation image (256 KB)
+// would not fit in LDS.
 template <int HID, int NST, bool GIVEN>
-__global__ __launch_bounds__(NTHREADS, 3 - NST) void is_fused_kernel(const IsArgs a) {
+__global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     constexpr int MS = 32 * NST;          // samples per pass
     constexpr int NP = NTHREADS / MS;     // threads per sample in the scoring phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -690,12 +690,13 @@ __global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks
 }
 
 // ----------------------------------------------------------------------------------------------
-// Plain MLP forward (predict_x / predict_y): 64 rows per pass.
+// Plain MLP forward (predict_x / predict_y): 32*NST rows per pass.
 // ----------------------------------------------------------------------------------------------
-template <int HID>
+template <int HID, int NST>
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, const float* in, int64_t N,
                                                            float* out) {
-    constexpr int MS = 64;
+    constexpr int MS = 32 * NST;
+    constexpr int NP = NTHREADS / MS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim);
     char* x0 = smem + cv.x0;
@@ -707,18 +708,19 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
     for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t npass = (N + MS - 1) / MS;
     for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
-        const int64_t row = ps * MS + lane;
+        const int sl = tid % MS, ph = tid / MS;   // row slot, dimension phase
+        const int64_t row = ps * MS + sl;
         __syncthreads();
-        for (int d = wave; d < m.in_dim; d += 4)
-            *(float*)(x0 + act_off<MS>(d >> 3, lane, (d >> 2) & 1) + 4 * (d & 3)) =
+        for (int d = ph; d < m.in_dim; d += NP)
+            *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) =
                 (row < N) ? in[row * m.in_dim + d] : 0.0f;
         __syncthreads();
 #ifdef RT_STAMPS
         Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
 #endif
-        mlp_core<HID, 2>(m, x0, act, wave, lane ST_ARG);
+        mlp_core<HID, NST>(m, x0, act, wave, lane ST_ARG);
         if (row < N)
-            for (int d = wave; d < m.out_dim; d += 4) out[row * m.out_dim + d] = mlp_out<MS>(m, part, d, lane);
+            for (int d = ph; d < m.out_dim; d += NP) out[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
     }
 }
 
@@ -743,7 +745,8 @@ struct DevBuf {
 struct HostMlp {
     bool set = false;
     int n_layers = 0;
-    int hid = 0;
+    int hid = 0;              // hidden width the kernels run at: max hidden width padded up to 128/256/512/1024
+    int nst = 2;              // sample tiles per wave (2: 64 samples per pass; 1: 32, for width 1024)
     std::vector<int> dims;
     std::vector<void*> dev;   // device allocations to free
     MlpArgs args;
@@ -755,8 +758,6 @@ struct HostMlp {
 struct rt_ctx {
     int device = 0;
     int cu_count = 0;
-    int nst = 2;   // sample tiles per wave: 2 = one 64-sample workgroup per CU.  (1 = two 32-sample workgroups per
-                   // CU was measured at 68 % of peak vs 85 %: it doubles the weight stream per MFMA)
     hipStream_t stream = nullptr;
     HostMlp mlp[2];
     DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
@@ -792,11 +793,12 @@ int ensure(rt_ctx* ctx, DevBuf& b, size_t bytes) {
     return RT_OK;
 }
 
-// Packs W [K x NF] (row-major, out = in @ W) into per-lane MFMA A-operand order:
+// Packs W [K x NF] (row-major, out = in @ W), zero-padded to [Kp x NFp], into per-lane MFMA A-operand order:
 //   packed[((kg*FTT + ft)*64 + lane)*4 + e] = W[8kg + 4h + e][32ft + i],  lane = 32h + i,
-// zero where k >= K or the feature >= NF.  FTT = ceil(NF/32), kg < ceil(K/8).
-void pack_layer(const float* W, int K, int NF, std::vector<float>& out) {
-    const int nkg = (K + 7) / 8, ftt = (NF + 31) / 32;
+// zero where k >= K or the feature >= NF.  FTT = ceil(NFp/32), kg < ceil(Kp/8).
+// Padding hidden widths with zero weights and biases is exact: a padded unit is lrelu(0) = 0 and feeds 0*w.
+void pack_layer(const float* W, int K, int NF, int Kp, int NFp, std::vector<float>& out) {
+    const int nkg = (Kp + 7) / 8, ftt = (NFp + 31) / 32;
     out.assign((size_t)nkg * ftt * 64 * 4, 0.0f);
     for (int kg = 0; kg < nkg; ++kg)
         for (int ft = 0; ft < ftt; ++ft)
@@ -831,11 +833,11 @@ int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
     return RT_OK;
 }
 
-template <int HID>
+template <int HID, int NST>
 int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* out, int grid, int lds) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_fwd_kernel<HID>,
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_fwd_kernel<HID, NST>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((mlp_fwd_kernel<HID>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, out);
+    hipLaunchKernelGGL((mlp_fwd_kernel<HID, NST>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, out);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -869,9 +871,9 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     if (rc) return rc;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     // work units: (query point, chunk of samples); aim for >= 128 units per CU-resident workgroup
-    const int nst = ctx->nst;
+    const int nst = G.nst;
     const int MS = 32 * nst;
-    const int grid_max = ctx->cu_count * (nst == 1 ? 2 : 1);
+    const int grid_max = ctx->cu_count;
     const int64_t passes = (S + MS - 1) / MS;
     int64_t want = (128ll * grid_max + N - 1) / N;
     if (want < 1) want = 1;
@@ -912,6 +914,7 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
         case 1282: rc = launch_is<128, 2>(ctx, a, given, grid, cv.total); break;
         case 2562: rc = launch_is<256, 2>(ctx, a, given, grid, cv.total); break;
         case 5122: rc = launch_is<512, 2>(ctx, a, given, grid, cv.total); break;
+        case 10241: rc = launch_is<1024, 1>(ctx, a, given, grid, cv.total); break;
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
     if (rc) return rc;
@@ -932,14 +935,16 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
     if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
     if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
     if (N == 0) return RT_OK;
-    const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim);
-    const int64_t npass = (N + 63) / 64;
+    const int ms = 32 * M.nst;
+    const Carve cv = carve_for(M.hid, ms, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const int64_t npass = (N + ms - 1) / ms;
     const int64_t gmax = (int64_t)ctx->cu_count * 2;
     const int grid = (int)(npass < gmax ? npass : gmax);
     switch (M.hid) {
-        case 128: return launch_fwd<128>(ctx, M.args, in, N, out, grid, cv.total);
-        case 256: return launch_fwd<256>(ctx, M.args, in, N, out, grid, cv.total);
-        case 512: return launch_fwd<512>(ctx, M.args, in, N, out, grid, cv.total);
+        case 128: return launch_fwd<128, 2>(ctx, M.args, in, N, out, grid, cv.total);
+        case 256: return launch_fwd<256, 2>(ctx, M.args, in, N, out, grid, cv.total);
+        case 512: return launch_fwd<512, 2>(ctx, M.args, in, N, out, grid, cv.total);
+        case 1024: return launch_fwd<1024, 1>(ctx, M.args, in, N, out, grid, cv.total);
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
 }
@@ -993,14 +998,15 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     if (!(lrelu_alpha >= 0.0f && lrelu_alpha <= 1.0f)) return fail(ctx, RT_EINVAL, "lrelu_alpha must be in [0, 1]");
     for (int l = 0; l <= n_layers; ++l) if (dims[l] < 1) return fail(ctx, RT_EINVAL, "dims must be >= 1");
     for (int l = 0; l < n_layers; ++l) if (!W[l] || !b[l]) return fail(ctx, RT_EINVAL, "NULL weight or bias");
-    const int hid = dims[1];
-    for (int l = 1; l < n_layers; ++l)
-        if (dims[l] != hid) return fail(ctx, RT_EUNSUPPORTED, "all hidden layers must have the same width");
-    if (hid != 128 && hid != 256 && hid != 512)
-        return fail(ctx, RT_EUNSUPPORTED, "hidden width must be 128, 256 or 512");
+    int hmax = 0;
+    for (int l = 1; l < n_layers; ++l) if (dims[l] > hmax) hmax = dims[l];
+    if (hmax > 1024) return fail(ctx, RT_EUNSUPPORTED, "hidden width > 1024");
+    // the kernels run at one of four widths; narrower / unequal hidden layers are zero-padded up (exact)
+    const int hid = hmax <= 128 ? 128 : hmax <= 256 ? 256 : hmax <= 512 ? 512 : 1024;
+    const int nst = hid == 1024 ? 1 : 2;
     if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 128");
     if (dims[n_layers] > MAX_OUT) return fail(ctx, RT_EUNSUPPORTED, "output dim > 128");
-    if (carve_for(hid, 64, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
+    if (carve_for(hid, 32 * nst, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
         return fail(ctx, RT_EUNSUPPORTED, "input dim too large for this hidden width (LDS budget of 160 KiB)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1008,6 +1014,7 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     free_mlp(M);
     M.n_layers = n_layers;
     M.hid = hid;
+    M.nst = nst;
     M.dims.assign(dims, dims + n_layers + 1);
     memset(&M.args, 0, sizeof(M.args));
     M.args.n_layers = n_layers;
@@ -1020,16 +1027,17 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     std::vector<float> packed, bias;
     for (int l = 0; l < n_layers; ++l) {
         const int K = dims[l], NF = dims[l + 1];
-        M.flops_per_row += 2.0 * (double)K * (double)NF;
-        pack_layer(W[l], K, NF, packed);
+        const int Kp = (l == 0) ? K : hid, NFp = (l == n_layers - 1) ? NF : hid;
+        M.flops_per_row += 2.0 * (double)K * (double)NF;   // algorithmic (unpadded) flops
+        pack_layer(W[l], K, NF, Kp, NFp, packed);
         // one extra zero k-group of padding keeps any speculative prefetch in bounds
-        const size_t pad = (size_t)((NF + 31) / 32) * 64 * 4;
+        const size_t pad = (size_t)((NFp + 31) / 32) * 64 * 4;
         packed.resize(packed.size() + pad, 0.0f);
         void* dw = nullptr;
         HIPCHK(ctx, hipMalloc(&dw, packed.size() * sizeof(float)));
         M.dev.push_back(dw);
         HIPCHK(ctx, hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-        bias.assign((size_t)((NF + 31) / 32) * 32, 0.0f);
+        bias.assign((size_t)((NFp + 31) / 32) * 32, 0.0f);
         memcpy(bias.data(), b[l], sizeof(float) * NF);
         void* db = nullptr;
         HIPCHK(ctx, hipMalloc(&db, bias.size() * sizeof(float)));

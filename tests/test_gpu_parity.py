@@ -74,6 +74,51 @@ def test_other_depths_and_widths(engine, hid, nl):
     assert np.array_equal(engine.mlp_forward(G, x), c_oracle.OracleMlp(ws, bs).forward(x, c_oracle.ORDER_KERNEL))
 
 
+def _pad_hidden(ws, bs, hid):
+    """Zero-pads every hidden layer to width hid (what rt_set_mlp does internally)."""
+    pw, pb = [], []
+    for l, (w, b) in enumerate(zip(ws, bs)):
+        kp = w.shape[0] if l == 0 else hid
+        nfp = w.shape[1] if l == len(ws) - 1 else hid
+        W = np.zeros((kp, nfp), np.float32)
+        W[:w.shape[0], :w.shape[1]] = w
+        B = np.zeros(nfp, np.float32)
+        B[:b.shape[0]] = b
+        pw.append(W)
+        pb.append(B)
+    return pw, pb
+
+
+@pytest.mark.parametrize("dims,hid", [([3, 100, 100, 5], 128), ([4, 64, 200, 32, 7], 256), ([2, 300, 512, 9], 512),
+                                      ([3, 1024, 1024, 1024, 6], 1024), ([5, 700, 600, 3], 1024)])
+def test_any_hidden_widths_by_exact_padding(engine, dims, hid):
+    """v2 accepts any g_units list (src/pyroundtrip/model.py:7,17-18): hidden layers are zero-padded to the
+    kernel width (128/256/512/1024).  Bit-exact against the oracle on explicitly padded weights, close to the
+    plain (unpadded, natural order) oracle; width 1024 runs the 32-sample-per-pass kernel."""
+    from conftest import glorot
+    ws, bs = glorot(dims, 21, 22)
+    engine.set_mlp(G, ws, bs)
+    x = np.random.RandomState(2).standard_normal((131, dims[0])).astype(np.float32)
+    got = engine.mlp_forward(G, x)
+    pw, pb = _pad_hidden(ws, bs, hid)
+    assert np.array_equal(got, c_oracle.OracleMlp(pw, pb).forward(x, c_oracle.ORDER_KERNEL, nthreads=8))
+    nat = c_oracle.OracleMlp(ws, bs).forward(x, c_oracle.ORDER_NATURAL, nthreads=8)
+    assert np.abs(got - nat).max() <= 3e-6 * np.abs(nat).max()
+    # and through the estimator
+    hw, hb = glorot([dims[-1], 128, dims[0]], 23, 24)
+    engine.set_mlp(H, hw, hb)
+    y = np.random.RandomState(3).standard_normal((3, dims[-1])) * 0.2
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    S = 200
+    est = engine.is_estimate(y, xhat, S, 0.3, 0.2, 1.0, seed=5)
+    xs = engine.draw_samples(xhat, S, 0.2, 1.0, seed=5).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(c_oracle.OracleMlp(pw, pb), y, xhat, xs, 0.3, 0.2, 1.0, True,
+                                              c_oracle.ORDER_KERNEL, 8)
+    np.testing.assert_allclose(est, want, rtol=1e-12)
+    c = engine.counters()
+    assert c["flops"] > 0
+
+
 @pytest.mark.parametrize("dx,dy", DIMS)
 @pytest.mark.parametrize("log", [True, False])
 def test_given_samples_match_oracle(engine, make_nets, dx, dy, log):
@@ -198,9 +243,12 @@ def test_empty_and_error_paths(engine, make_nets):
     try:
         with pytest.raises(_lib.RtError):                       # MLP not set
             fresh.is_estimate(np.zeros((1, 2)), np.zeros((1, 2), np.float32), 10, 0.1, 0.1)
-        with pytest.raises(_lib.RtError):                       # hidden width not supported by the fused kernel
-            fresh.set_mlp(G, [np.zeros((2, 100), np.float32), np.zeros((100, 2), np.float32)],
-                          [np.zeros(100, np.float32), np.zeros(2, np.float32)])
+        with pytest.raises(_lib.RtError):                       # hidden width beyond the kernels' 1024
+            fresh.set_mlp(G, [np.zeros((2, 1100), np.float32), np.zeros((1100, 2), np.float32)],
+                          [np.zeros(1100, np.float32), np.zeros(2, np.float32)])
+        with pytest.raises(_lib.RtError):                       # output dim > 128
+            fresh.set_mlp(G, [np.zeros((2, 128), np.float32), np.zeros((128, 200), np.float32)],
+                          [np.zeros(128, np.float32), np.zeros(200, np.float32)])
         with pytest.raises(_lib.RtError):                       # alpha outside [0, 1]
             fresh.set_mlp(G, gw, gb, alpha=1.5)
     finally:
