@@ -112,7 +112,8 @@ static int k_sequence(const rto_mlp* m, int l, int order, int* seq, int* qstart,
  *   order 1: the summation order of the HIP kernel (rt_is.hip): k-groups of 8; inside a group
  *            k = 8g+e, 8g+4+e for e = 0..3 (the two lane halves of v_mfma_f32_32x32x2_f32); the output
  *            layer is split into four K-quarters whose partial sums are added ((p0+p1)+p2)+p3.
- * Bias is added after the matmul (fully_connected = matmul then bias_add), then leaky_relu on hidden layers.
+ * Bias is added after the matmul (fully_connected = matmul then bias_add), then leaky_relu on hidden layers;
+ * order 1 starts a hidden layer's chain FROM the bias instead (what the kernel does, see below).
  * in: [R][ldi], out: [R][ldo], tmp: [R][ldo].
  */
 static void dense_block(const rto_mlp* m, int l, int R, const float* in, int ldi, float* out, int ldo,
@@ -124,8 +125,11 @@ static void dense_block(const rto_mlp* m, int l, int R, const float* in, int ldi
     k_sequence(m, l, order, seq, qstart, &nq);
     for (int q = 0; q < nq; ++q) {
         float* dst = (q == 0) ? out : tmp;
+        /* order 1, hidden layers: the kernel's first MFMA of a layer takes the bias as its C operand, so the
+         * chain starts from the bias instead of adding it at the end */
+        const int bias_first = (order == 1 && !last);
         for (int r = 0; r < R; ++r)
-            for (int f = 0; f < NF; ++f) dst[r * ldo + f] = 0.0f;
+            for (int f = 0; f < NF; ++f) dst[r * ldo + f] = bias_first ? m->b[l][f] : 0.0f;
         for (int i = qstart[q]; i < qstart[q + 1]; ++i) {
             const int k = seq[i];
             const float* w = W + (size_t)k * NF;
@@ -143,6 +147,7 @@ static void dense_block(const rto_mlp* m, int l, int R, const float* in, int ldi
     for (int r = 0; r < R; ++r) {
         float* o = out + r * ldo;
         if (last) for (int f = 0; f < NF; ++f) o[f] = o[f] + b[f];
+        else if (order == 1) for (int f = 0; f < NF; ++f) o[f] = lrelu(o[f], m->alpha);
         else for (int f = 0; f < NF; ++f) o[f] = lrelu(o[f] + b[f], m->alpha);
     }
 }

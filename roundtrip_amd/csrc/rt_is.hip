@@ -88,7 +88,7 @@ __device__ __forceinline__ int act_off(int kg, int s, int hh) {
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
 template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
-                                           const f32x4 (&b)[NST]) {
+                                           const f32x4 (&b)[NST], const f32x16* cinit = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -96,8 +96,8 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
         for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
             for (int st = 0; st < NST; ++st)
-                acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ft][e], b[st][e],
-                                                                   (FIRST && e == 0) ? zero : acc[ft][st], 0, 0, 0);
+                acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    a[ft][e], b[st][e], (FIRST && e == 0) ? (cinit ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
 }
 
 // acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
@@ -166,10 +166,10 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], con
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
 template <int NFT, int NST>
 __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const WSrc& wl,
-                                                 int ftt, int nkg, const char* bl) {
+                                                 int ftt, int nkg, const char* bl, const f32x16* cinit) {
     f32x4 a[NFT], b[NST];
     load_group<NFT, NST>(a, b, wl, ftt * 64, bl, 0);
-    mfma_group<NFT, NST, true>(acc, a, b);
+    mfma_group<NFT, NST, true>(acc, a, b, cinit);
 #pragma unroll 1
     for (int kg = 1; kg < nkg; ++kg) {
         load_group<NFT, NST>(a, b, wl, ftt * 64, bl, kg);
@@ -184,9 +184,10 @@ __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const 
 template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
-                                           const WSrc& wl, int wstride, const char* bl, int kgn) {
+                                           const WSrc& wl, int wstride, const char* bl, int kgn,
+                                           const f32x16* cinit = nullptr) {
     load_group<NFT, NST, RT_ABL>(an, bn, wl, wstride, bl, kgn);
-    mfma_group<NFT, NST, FIRST>(acc, ac, bc);
+    mfma_group<NFT, NST, FIRST>(acc, ac, bc, cinit);
     constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
 #if RT_SCHED == 0
 #pragma unroll
@@ -258,7 +259,7 @@ __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f
 template <int NFT, int NST>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
                                           f32x4 (&a2)[NFT], const WSrc& wl,
-                                          int ftt, int nkg, const char* bl) {
+                                          int ftt, int nkg, const char* bl, const f32x16* cinit) {
     f32x4 a3[NFT], b0[NST], b1[NST], b2[NST], b3[NST];
     const int wstride = ftt * 64;
     const int lastg = nkg - 1;
@@ -271,7 +272,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
     if (RT_ABL) load_group<NFT, NST>(a3, b3, wl, wstride, bl, 3);
     __builtin_amdgcn_sched_barrier(0);
     // first four k-groups peeled: their first MFMAs start the accumulators from the constant 0
-    pipe_stage<NFT, NST, true>(acc, a3, b3, a0, b0, wl, wstride, bl, 3);
+    pipe_stage<NFT, NST, true>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
     pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(4, lastg));
     pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(5, lastg));
     pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(6, lastg));
@@ -288,22 +289,33 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
 // Requested BEFORE the layer's K loop (sched_barrier keeps hipcc from sinking the loads to their use, where
 // each would expose an L2 round trip), consumed by store_act after it.
 template <int NFT>
-__device__ __forceinline__ void load_bias(f32x4 (&bv)[NFT][4], const float* __restrict__ bias, int wave, int lane) {
+__device__ __forceinline__ void load_bias(f32x16 (&bv)[NFT], const float* __restrict__ bias, int wave, int lane) {
     const int h = lane >> 5;
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            bv[ft][q] = *(const f32x4*)(bias + 32 * (wave * NFT + ft) + 8 * q + 4 * h);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *(const f32x4*)(bias + 32 * (wave * NFT + ft) + 8 * q + 4 * h);
+            bv[ft][4 * q] = t[0]; bv[ft][4 * q + 1] = t[1]; bv[ft][4 * q + 2] = t[2]; bv[ft][4 * q + 3] = t[3];
+        }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Hidden-layer epilogue: act = lrelu(acc + bias), written in the next layer's B-operand image.
+// One v_max_f32.  fmaxf() on a value that comes straight out of an MFMA makes hipcc put a canonicalising
+// v_max in front of it (128 extra instructions per epilogue); the bare instruction has fmaxf's NaN behaviour.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Hidden-layer epilogue: act = lrelu(acc), written in the next layer's B-operand image.  The bias is already in
+// acc: the layer's first MFMA takes it as its C operand (mfma_group's cinit), so a feature's value is the fp32
+// fmaf chain  fma(w_kn, x_kn, ... fma(w_k0, x_k0, bias)).
 // C/D map of the 32x32 MFMA: lane (h, j): column j = sample; register r = row (r&3) + 8(r>>2) + 4h = feature.
 // Registers 4q..4q+3 of tile (FT, st) are features 32FT + 8q + 4h + (0..3) = next-layer k-group 4FT+q, half h.
 template <int NFT, int NST>
-__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], const f32x4 (&bv)[NFT][4],
-                                          float alpha, char* act, int wave, int lane) {
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane) {
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
 #pragma unroll
@@ -317,11 +329,10 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], const f32x4 (
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     // two lanes' worth per instruction: v_pk_add_f32 / v_pk_mul_f32 (same IEEE results)
-                    const f32x2 t = f32x2{acc[ft][st][4 * q + e], acc[ft][st][4 * q + e + 1]} +
-                                    f32x2{bv[ft][q][e], bv[ft][q][e + 1]};
+                    const f32x2 t = f32x2{acc[ft][st][4 * q + e], acc[ft][st][4 * q + e + 1]};
                     const f32x2 u = t * f32x2{alpha, alpha};
-                    v[e] = fmaxf(t[0], u[0]);
-                    v[e + 1] = fmaxf(t[1], u[1]);
+                    v[e] = vmax(t[0], u[0]);
+                    v[e + 1] = vmax(t[1], u[1]);
                 }
                 *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 * st + j, h)) = v;
             }
@@ -340,7 +351,7 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
     const WSrc wl = make_wsrc(m.wp[m.n_layers - 1] + (size_t)(wave * kq) * NT * 256, lane);
     f32x4 a0[NT], a1[NT], a2[NT];
     prefetch_a<NT>(a0, a1, a2, wl, NT * 64);
-    gemm_tile<NT, NST>(acc, a0, a1, a2, wl, NT, kq, act + act_off<MS>(wave * kq, j, h));
+    gemm_tile<NT, NST>(acc, a0, a1, a2, wl, NT, kq, act + act_off<MS>(wave * kq, j, h), nullptr);
     __syncthreads();   // every wave is done reading the activation image
     const int od = m.out_dim;
 #pragma unroll
@@ -366,10 +377,10 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc[NFT][NST];
-    f32x4 bv[NFT][4];
+    f32x16 bv[NFT];
     load_bias<NFT>(bv, m.bp[0], wave, lane);
     gemm_tile_simple<NFT, NST>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
-                               x0 + act_off<MS>(0, j, h));
+                               x0 + act_off<MS>(0, j, h), bv);
     ST(1)
     const int nhid = m.n_layers - 1;
     f32x4 a0[NFT], a1[NFT], a2[NFT];
@@ -378,13 +389,13 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
         if (l + 1 < nhid) prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
-        store_act<NFT, NST>(acc, bv, m.alpha, act, wave, lane);
+        store_act<NFT, NST>(acc, m.alpha, act, wave, lane);
         if (l + 1 < nhid) load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
         ST(3)
         __syncthreads();
         ST(4)
         if (l + 1 < nhid)
-            gemm_tile<NFT, NST>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h));
+            gemm_tile<NFT, NST>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
         ST(5)
     }
     float* part = (float*)act;
