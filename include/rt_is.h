@@ -77,6 +77,16 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims,
  * (main_density_est.py:222-234 / 237-249; v2: self.g_net(...) / self.e_net(...), roundtrip.py:249,283). */
 int rt_mlp_forward(rt_ctx* ctx, int which, const float* in, int64_t N, float* out);
 
+/* Jacobian of MLP_which at every row of `in`, by forward-mode differentiation on the GPU.  Replaces get_jacobian
+ * (main_density_est.py:252-263: sess.run(self.J), with self.J = batch_jacobian(self.y_, self.x), :65; v2
+ * tf.GradientTape.batch_jacobian, src/pyroundtrip/roundtrip.py:312-324), which the Laplace estimator
+ * estimate_py_with_CF (:351-387) calls at x = H(y).
+ *   in   N x dims[0] float32        out  N x dims[L] float32, MLP_which(in) (may be NULL)
+ *   J    N x dims[L] x dims[0] float32, J[n][i][j] = d out[n][i] / d in[n][j]  (the reference's (N, y_dim, x_dim))
+ * leaky_relu'(t) is taken as 1 for t > 0 and lrelu_alpha otherwise.  Hidden width <= 512 only (RT_EUNSUPPORTED
+ * above). */
+int rt_mlp_jacobian(rt_ctx* ctx, int which, const float* in, int64_t N, float* out, float* J);
+
 /* xhat = H(y): rt_mlp_forward(ctx, RT_MLP_H, ...) under the name the estimator uses
  * (main_density_est.py:320). */
 int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);

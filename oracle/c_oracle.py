@@ -25,6 +25,8 @@ def _load():
     lib.rto_mlp_create.argtypes = [C.c_int, C.POINTER(C.c_int32), fpp, fpp, C.c_float]
     lib.rto_mlp_destroy.argtypes = [C.c_void_p]
     lib.rto_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]
+    lib.rto_mlp_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.rto_mlp_jacobian.restype = None
     lib.rto_t_logpdf.restype = C.c_double
     lib.rto_t_logpdf.argtypes = [C.c_double, C.c_double, C.c_double]
     lib.rto_is_estimate_given_samples.restype = C.c_int
@@ -86,6 +88,15 @@ class OracleMlp(object):
         out = np.empty((x.shape[0], self.output_dim), dtype=np.float32)
         lib().rto_mlp_forward(self._h, x.ctypes.data, x.shape[0], out.ctypes.data, int(order), int(nthreads))
         return out
+
+    def jacobian(self, x, order=ORDER_NATURAL, nthreads=1):
+        """(out (N, out_dim), J (N, out_dim, in_dim)) float32 — get_jacobian, main_density_est.py:252-263."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.input_dim)
+        out = np.empty((x.shape[0], self.output_dim), dtype=np.float32)
+        J = np.empty((x.shape[0], self.output_dim, self.input_dim), dtype=np.float32)
+        lib().rto_mlp_jacobian(self._h, x.ctypes.data, x.shape[0], out.ctypes.data, J.ctypes.data, int(order),
+                               int(nthreads))
+        return out, J
 
 
 def is_estimate_given_samples(g, y, xhat, xs, sd_y, scale, df=1.0, log=True, order=ORDER_NATURAL, nthreads=1):

@@ -17,6 +17,7 @@
  *                                 v2 twin src/pyroundtrip/model.py:29-50
  *   score_point                   py_given_x main_density_est.py:278-290, w_likelihood_ratio :292-307,
  *                                 reduction :339-345 (v2: roundtrip.py:241-270, 303-309)
+ *   rto_mlp_jacobian              get_jacobian main_density_est.py:252-263 (self.J, :65), forward mode
  *   rto_draw_samples              NOT the reference's sampler (numpy's global MT19937 stream, :316-318,
  *                                 lives in is_ref.py): it restates this repo's Philox4x32-10 proposal
  *                                 sampler so that tests can check the GPU draws bit-for-bit-ish.
@@ -199,6 +200,70 @@ void rto_mlp_forward(void* p, const float* in, int64_t N, float* out, int order,
             mlp_block(m, R, in + r0 * m->dims[0], out + r0 * m->dims[m->n_layers], scratch, order);
         }
         free(scratch);
+    }
+}
+
+/*
+ * get_jacobian (main_density_est.py:252-263: sess.run(self.J), self.J = batch_jacobian(self.y_, self.x) :65; v2
+ * tf.GradientTape.batch_jacobian, src/pyroundtrip/roundtrip.py:312-324), restated as forward-mode differentiation
+ * of the same float32 MLP: for input direction d the tangent of a dense layer is the same fmaf chain over k
+ * without the bias, and leaky_relu'(t) is 1 where t > 0 and alpha elsewhere (TensorFlow's reverse mode computes
+ * the same products in another order; at exactly t == 0 TF's maximum/minimum gradient convention gives 0, a
+ * measure-zero difference).  out: N x dims[L] (may be NULL), J: N x dims[L] x dims[0], row-major.
+ * order as in dense_block (order 1 = the HIP kernel's summation order: bit-exact comparisons).
+ */
+void rto_mlp_jacobian(void* p, const float* in, int64_t N, float* out, float* J, int order, int nthreads) {
+    const rto_mlp* m = (const rto_mlp*)p;
+    const int L = m->n_layers, id = m->dims[0], od = m->dims[L];
+    const int mw = max_width(m);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        float* a = (float*)malloc(sizeof(float) * 4 * (size_t)mw);
+        float *ta = a + mw, *b = a + 2 * mw, *tb = a + 3 * mw;
+        int* seq = (int*)malloc(sizeof(int) * (size_t)mw);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int64_t n = 0; n < N; ++n)
+            for (int d = 0; d < id; ++d) {
+                float *pa = a, *pta = ta, *pb = b, *ptb = tb;
+                for (int k = 0; k < id; ++k) { pa[k] = in[n * id + k]; pta[k] = (k == d) ? 1.0f : 0.0f; }
+                for (int l = 0; l < L; ++l) {
+                    const int NF = m->dims[l + 1], last = (l == L - 1);
+                    const float* W = m->W[l];
+                    int qstart[5], nq;
+                    k_sequence(m, l, order, seq, qstart, &nq);
+                    const int bias_first = (order == 1 && !last);
+                    for (int f = 0; f < NF; ++f) {
+                        float ps = 0.0f, ts = 0.0f;
+                        for (int q = 0; q < nq; ++q) {
+                            float cp = (bias_first && q == 0) ? m->b[l][f] : 0.0f, ct = 0.0f;
+                            for (int i = qstart[q]; i < qstart[q + 1]; ++i) {
+                                const int k = seq[i];
+                                cp = fmaf(pa[k], W[(size_t)k * NF + f], cp);
+                                ct = fmaf(pta[k], W[(size_t)k * NF + f], ct);
+                            }
+                            if (q == 0) { ps = cp; ts = ct; } else { ps = ps + cp; ts = ts + ct; }
+                        }
+                        if (last) { pb[f] = ps + m->b[l][f]; ptb[f] = ts; }
+                        else {
+                            const float t = bias_first ? ps : ps + m->b[l][f];
+                            pb[f] = lrelu(t, m->alpha);
+                            ptb[f] = (t > 0.0f) ? ts : ts * m->alpha;
+                        }
+                    }
+                    float* x;
+                    x = pa; pa = pb; pb = x;
+                    x = pta; pta = ptb; ptb = x;
+                }
+                if (d == 0 && out) for (int f = 0; f < od; ++f) out[n * od + f] = pa[f];
+                for (int f = 0; f < od; ++f) J[((size_t)n * od + f) * id + d] = pta[f];
+            }
+        free(a);
+        free(seq);
     }
 }
 

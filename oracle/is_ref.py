@@ -9,7 +9,8 @@ calls the reference's own third-party arithmetic — numpy's legacy global Rando
 multivariate_normal) and scipy.stats.t.logpdf — statement by statement, single-threaded so the draw
 order is defined; only the TensorFlow dense layers are restated (float32 `x @ W + b`, leaky-ReLU).
 
-Follows /root/reference/main_density_est.py:266-348 (v2 twin: src/pyroundtrip/roundtrip.py:229-310).
+Follows /root/reference/main_density_est.py:266-348 (v2 twin: src/pyroundtrip/roundtrip.py:229-310) and, for the
+Laplace estimator, :252-263 and :351-387 (v2: roundtrip.py:312-369).
 """
 import numpy as np
 from scipy.stats import t
@@ -124,6 +125,50 @@ def estimate_py_with_IS(g_net, h_net, y_points, sd_y=0.5, scale=0.5, sample_size
     if return_samples:
         return py_est, np.stack(kept), x_points_
     return py_est
+
+
+def get_jacobian(net, x):
+    """get_jacobian (main_density_est.py:252-263; self.J = batch_jacobian(self.y_, self.x), :65): (N, y_dim, x_dim)
+    float64 container holding float32 values.  TensorFlow's autodiff is restated as float32 forward mode: the
+    tangent of a dense layer is T @ W, and leaky_relu'(t) is 1 for t > 0, alpha otherwise."""
+    fc = np.asarray(x, dtype=np.float32)
+    N, x_dim = fc.shape
+    tan = np.broadcast_to(np.eye(x_dim, dtype=np.float32), (N, x_dim, x_dim)).copy()   # [n, direction, feature]
+    for w, b in zip(net.weights[:-1], net.biases[:-1]):
+        pre = fc @ w + b
+        tan = (tan @ w) * np.where(pre > 0, np.float32(1.0), np.float32(net.alpha))[:, None, :]
+        fc = leaky_relu(pre, net.alpha)
+    tan = tan @ net.weights[-1]
+    jcob_pred = np.zeros(shape=(N, net.output_dim, x_dim))
+    jcob_pred[:] = tan.transpose((0, 2, 1))
+    return jcob_pred
+
+
+def estimate_py_with_CF(g_net, h_net, y_points, sd_y=0.5, log=True):
+    """Laplace / closed-form estimator, main_density_est.py:351-387 statement by statement (v2 twin:
+    src/pyroundtrip/roundtrip.py:327-369).  Note the reference's log=False branch carries an extra sd_y**y_dim
+    factor that its log=True branch does not (:382 vs :384); both are reproduced as written."""
+    x_dim, y_dim = g_net.input_dim, g_net.output_dim
+    y_points = np.asarray(y_points, dtype=np.float64)
+    x_points_ = predict(h_net, y_points, x_dim)              # :363
+    y_points__ = predict(g_net, x_points_, y_dim)            # :364
+    rt_error = np.sum((y_points - y_points__) ** 2, axis=1)  # :365
+    jacob_mat = get_jacobian(g_net, x_points_)               # :367
+    jacob_mat_transpose = jacob_mat.transpose((0, 2, 1))     # :369
+    A = list(map(lambda x, y: np.dot(x, y), jacob_mat_transpose, jacob_mat))                 # :371
+    b = list(map(lambda x, y: np.dot(x, y), jacob_mat_transpose, y_points - y_points__))     # :373
+    Sigma = list(map(lambda x: np.linalg.inv(np.eye(x_dim) + x / sd_y ** 2), A))             # :375
+    Sigma_inv = list(map(lambda x: np.eye(x_dim) + x / sd_y ** 2, A))                        # :376
+    mu = list(map(lambda x, y, z: x.dot(y / sd_y ** 2 - z), Sigma, b, x_points_))            # :378
+    c_y = list(map(lambda x, y, z, w: np.sum(x ** 2) + y / sd_y ** 2 - z.T.dot(w).dot(z),
+                   x_points_, rt_error, mu, Sigma_inv))                                      # :380
+    if log:
+        py_est = list(map(lambda x, y: -y_dim * np.log(np.sqrt(2 * np.pi) * sd_y) + 0.5 * np.log(np.linalg.det(x))
+                          - 0.5 * y, Sigma, c_y))                                            # :382
+    else:
+        py_est = list(map(lambda x, y: 1. / (np.sqrt(2 * np.pi) * sd_y) ** y_dim * sd_y ** y_dim
+                          * np.sqrt(np.linalg.det(x)) * np.exp(-0.5 * y), Sigma, c_y))       # :384
+    return np.array(py_est)
 
 
 def create_2d_grid_data(x1_min, x1_max, x2_min, x2_max, n=100):

@@ -49,7 +49,11 @@ def make(name, dx, dy, y, sd, scale, S, df=1, seed=1234, bias_seed=None, extra=N
                                          x_samples=xs)
     d = dict(dx=dx, dy=dy, weight_seed=seed, bias_seed=-1 if bias_seed is None else bias_seed, y=y,
              xhat=xhat.astype(np.float32), sd=sd, scale=scale, S=S, df=df, log_est=log_est, lin_est=lin_est,
-             xs_head=xs[:, :8, :].copy(), g_of_xhat=g(xhat.astype(np.float32)))
+             xs_head=xs[:, :8, :].copy(), g_of_xhat=g(xhat.astype(np.float32)),
+             # Laplace estimator (main_density_est.py:351-387) and the Jacobian it uses (:252-263)
+             jac_at_xhat=is_ref.get_jacobian(g, xhat),
+             cf_log_est=is_ref.estimate_py_with_CF(g, h, y, sd_y=sd, log=True),
+             cf_lin_est=is_ref.estimate_py_with_CF(g, h, y, sd_y=sd, log=False))
     if extra:
         d.update(extra)
     np.savez(os.path.join(OUT, name + ".npz"), **d)

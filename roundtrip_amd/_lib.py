@@ -16,7 +16,7 @@ RT_MLP_H = 1
 
 # every symbol include/rt_is.h declares (tests check the library exports each one)
 SYMBOLS = (
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_encode",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_mlp_jacobian", "rt_encode",
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
 )
@@ -52,6 +52,7 @@ def load():
     lib.rt_last_error.argtypes = [vp]
     lib.rt_set_mlp.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int32), fpp, fpp, C.c_float]
     lib.rt_mlp_forward.argtypes = [vp, C.c_int, vp, i64, vp]
+    lib.rt_mlp_jacobian.argtypes = [vp, C.c_int, vp, i64, vp, vp]
     lib.rt_encode.argtypes = [vp, vp, i64, vp]
     lib.rt_is_estimate.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, C.c_int, vp]
     lib.rt_is_estimate_multi.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, dbl, dbl, C.c_uint64, C.c_int, vp]
@@ -124,6 +125,20 @@ class Engine(object):
         out = np.empty((x.shape[0], dims[-1]), dtype=np.float32)
         self._chk(self._lib.rt_mlp_forward(self._h, int(which), x.ctypes.data, x.shape[0], out.ctypes.data))
         return out
+
+    def mlp_jacobian(self, which, x):
+        """(MLP(x) (N, out), J (N, out, in)) float32: get_jacobian (main_density_est.py:252-263) on the GPU."""
+        dims = self.dims.get(int(which))
+        if dims is None:
+            raise RtError("MLP %d has not been set" % which)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != dims[0]:
+            raise ValueError("expected shape (N, %d), got %r" % (dims[0], x.shape))
+        out = np.empty((x.shape[0], dims[-1]), dtype=np.float32)
+        J = np.empty((x.shape[0], dims[-1], dims[0]), dtype=np.float32)
+        self._chk(self._lib.rt_mlp_jacobian(self._h, int(which), x.ctypes.data, x.shape[0], out.ctypes.data,
+                                            J.ctypes.data))
+        return out, J
 
     def _g_dims(self):
         dims = self.dims.get(RT_MLP_G)

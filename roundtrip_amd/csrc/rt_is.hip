@@ -86,7 +86,8 @@ __device__ __forceinline__ int act_off(int kg, int s, int hh) {
 // ----------------------------------------------------------------------------------------------
 // FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
-template <int NFT, int NST, bool FIRST = false>
+// JVP: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.
+template <int NFT, int NST, bool FIRST = false, bool JVP = false>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
                                            const f32x4 (&b)[NST], const f32x16* cinit = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -97,7 +98,8 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
 #pragma unroll
             for (int st = 0; st < NST; ++st)
                 acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    a[ft][e], b[st][e], (FIRST && e == 0) ? (cinit ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
+                    a[ft][e], b[st][e],
+                    (FIRST && e == 0) ? ((cinit && !(JVP && st == 1)) ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
 }
 
 // acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
@@ -164,12 +166,12 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], con
 }
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
-template <int NFT, int NST>
+template <int NFT, int NST, bool JVP = false>
 __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const WSrc& wl,
                                                  int ftt, int nkg, const char* bl, const f32x16* cinit) {
     f32x4 a[NFT], b[NST];
     load_group<NFT, NST>(a, b, wl, ftt * 64, bl, 0);
-    mfma_group<NFT, NST, true>(acc, a, b, cinit);
+    mfma_group<NFT, NST, true, JVP>(acc, a, b, cinit);
 #pragma unroll 1
     for (int kg = 1; kg < nkg; ++kg) {
         load_group<NFT, NST>(a, b, wl, ftt * 64, bl, kg);
@@ -181,13 +183,13 @@ __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const 
 // of the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
 // the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
 // behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
-template <int NFT, int NST, bool FIRST = false>
+template <int NFT, int NST, bool FIRST = false, bool JVP = false>
 __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
                                            const WSrc& wl, int wstride, const char* bl, int kgn,
                                            const f32x16* cinit = nullptr) {
     load_group<NFT, NST, RT_ABL>(an, bn, wl, wstride, bl, kgn);
-    mfma_group<NFT, NST, FIRST>(acc, ac, bc, cinit);
+    mfma_group<NFT, NST, FIRST, JVP>(acc, ac, bc, cinit);
     constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
 #if RT_SCHED == 0
 #pragma unroll
@@ -256,7 +258,7 @@ __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f
 // nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
 // MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
 // a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
-template <int NFT, int NST>
+template <int NFT, int NST, bool JVP = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
                                           f32x4 (&a2)[NFT], const WSrc& wl,
                                           int ftt, int nkg, const char* bl, const f32x16* cinit) {
@@ -272,7 +274,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
     if (RT_ABL) load_group<NFT, NST>(a3, b3, wl, wstride, bl, 3);
     __builtin_amdgcn_sched_barrier(0);
     // first four k-groups peeled: their first MFMAs start the accumulators from the constant 0
-    pipe_stage<NFT, NST, true>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
+    pipe_stage<NFT, NST, true, JVP>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
     pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(4, lastg));
     pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(5, lastg));
     pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(6, lastg));
@@ -314,10 +316,33 @@ __device__ __forceinline__ float vmax(float a, float b) {
 // fmaf chain  fma(w_kn, x_kn, ... fma(w_k0, x_k0, bias)).
 // C/D map of the 32x32 MFMA: lane (h, j): column j = sample; register r = row (r&3) + 8(r>>2) + 4h = feature.
 // Registers 4q..4q+3 of tile (FT, st) are features 32FT + 8q + 4h + (0..3) = next-layer k-group 4FT+q, half h.
-template <int NFT, int NST>
+// JVP (NST == 2): tile 0 holds primal pre-activations t, tile 1 the tangent pre-activations dt of the SAME rows in
+// the same lanes and registers, so the tangent's activation is lrelu'(t) * dt with no cross-lane traffic:
+// slope 1 where t > 0, alpha elsewhere.
+template <int NFT, int NST, bool JVP = false>
 __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane) {
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
+    if constexpr (JVP) {
+        static_assert(NST == 2, "JVP pairs sample tile 0 (primal) with sample tile 1 (tangent)");
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const int FT = wave * NFT + ft;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[ft][0][4 * q + e], dt = acc[ft][1][4 * q + e];
+                    v0[e] = vmax(t, t * alpha);
+                    v1[e] = (t > 0.0f) ? dt : dt * alpha;
+                }
+                *(f32x4*)(act + act_off<MS>(4 * FT + q, j, h)) = v0;
+                *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 + j, h)) = v1;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
         const int FT = wave * NFT + ft;
@@ -370,7 +395,7 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
 // Runs the MLP on the MS samples whose (padded) inputs sit in the x0 image.  On return
 // part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 256 threads.
-template <int HID, int NST>
+template <int HID, int NST, bool JVP = false>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane ST_PARAM) {
     constexpr int NFT = HID / 128;
     constexpr int FTT = HID / 32;
@@ -379,8 +404,8 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     f32x16 acc[NFT][NST];
     f32x16 bv[NFT];
     load_bias<NFT>(bv, m.bp[0], wave, lane);
-    gemm_tile_simple<NFT, NST>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
-                               x0 + act_off<MS>(0, j, h), bv);
+    gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
+                                    x0 + act_off<MS>(0, j, h), bv);
     ST(1)
     const int nhid = m.n_layers - 1;
     f32x4 a0[NFT], a1[NFT], a2[NFT];
@@ -389,13 +414,13 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
         if (l + 1 < nhid) prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
-        store_act<NFT, NST>(acc, m.alpha, act, wave, lane);
+        store_act<NFT, NST, JVP>(acc, m.alpha, act, wave, lane);
         if (l + 1 < nhid) load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
         ST(3)
         __syncthreads();
         ST(4)
         if (l + 1 < nhid)
-            gemm_tile<NFT, NST>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
+            gemm_tile<NFT, NST, JVP>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
         ST(5)
     }
     float* part = (float*)act;
@@ -409,11 +434,15 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
 }
 
 template <int MS>
-__device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
+__device__ __forceinline__ float mlp_out_nobias(const MlpArgs& m, const float* part, int d, int s) {
     const int od = m.out_dim;
     const float p0 = part[(0 * od + d) * MS + s], p1 = part[(1 * od + d) * MS + s];
     const float p2 = part[(2 * od + d) * MS + s], p3 = part[(3 * od + d) * MS + s];
-    return ((p0 + p1) + p2) + p3 + m.bp[m.n_layers - 1][d];
+    return ((p0 + p1) + p2) + p3;
+}
+template <int MS>
+__device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
+    return mlp_out_nobias<MS>(m, part, d, s) + m.bp[m.n_layers - 1][d];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -735,6 +764,57 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Jacobian of an MLP by forward-mode differentiation (get_jacobian, main_density_est.py:252-263, the
+// tf.gradients graph :65; v2 batch_jacobian, roundtrip.py:312-324).  One pass = 32 rows x one input
+// direction d: sample tile 0 carries the rows' primal inputs, sample tile 1 the unit tangent e_d for the same
+// rows, so column d of every row's Jacobian comes out of tile 1.  J is N x out_dim x in_dim, row-major.
+// The primal is recomputed for every d (in_dim x the work of a plain forward; this path runs once per QUERY
+// POINT, not per sample, so it is ~1e-4 of the IS estimate's work).
+// ----------------------------------------------------------------------------------------------
+template <int HID>
+__global__ __launch_bounds__(NTHREADS) void mlp_jvp_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                           float* yout, float* J) {
+    constexpr int MS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim);
+    char* x0 = smem + cv.x0;
+    char* act = smem + cv.act;
+    const float* part = (const float*)act;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t npass = ((N + 31) / 32) * m.in_dim;
+    const int sl = tid & 63, ph = tid >> 6;       // column slot, dimension phase
+    for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
+        const int64_t blk = ps / m.in_dim;
+        const int dir = (int)(ps - blk * m.in_dim);
+        const int64_t row = blk * 32 + (sl & 31);
+        __syncthreads();
+        for (int d = ph; d < m.in_dim; d += 4) {
+            float v;
+            if (sl < 32) v = (row < N) ? in[row * m.in_dim + d] : 0.0f;
+            else v = (d == dir) ? 1.0f : 0.0f;
+            *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = v;
+        }
+        __syncthreads();
+#ifdef RT_STAMPS
+        Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+#endif
+        mlp_core<HID, 2, true>(m, x0, act, wave, lane ST_ARG);
+        if (row < N) {
+            if (sl < 32) {
+                if (dir == 0 && yout)
+                    for (int d = ph; d < m.out_dim; d += 4) yout[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
+            } else {
+                for (int d = ph; d < m.out_dim; d += 4)
+                    J[(row * m.out_dim + d) * m.in_dim + dir] = mlp_out_nobias<MS>(m, part, d, sl);
+            }
+        }
+    }
+}
+
 __global__ void draw_samples_kernel(SamplerArgs sa, const float* xhat, int64_t N, int64_t y_index_base,
                                     int64_t S, int dx, float* xs) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -853,6 +933,15 @@ int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float*
     return RT_OK;
 }
 
+template <int HID>
+int launch_jvp(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_jvp_kernel<HID>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((mlp_jvp_kernel<HID>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, yout, J);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArgs& sa) {
     if (!(scale > 0.0) || !(df > 0.0) || !isfinite(scale) || !isfinite(df))
         return fail(ctx, RT_EINVAL, "scale and df must be positive and finite");
@@ -956,6 +1045,25 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
         case 256: return launch_fwd<256, 2>(ctx, M.args, in, N, out, grid, cv.total);
         case 512: return launch_fwd<512, 2>(ctx, M.args, in, N, out, grid, cv.total);
         case 1024: return launch_fwd<1024, 1>(ctx, M.args, in, N, out, grid, cv.total);
+        default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
+    }
+}
+
+int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout, float* J) {
+    if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
+    HostMlp& M = ctx->mlp[which];
+    if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N == 0) return RT_OK;
+    if (M.nst != 2) return fail(ctx, RT_EUNSUPPORTED, "Jacobian needs hidden width <= 512 (64-column passes)");
+    const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const int64_t npass = ((N + 31) / 32) * M.args.in_dim;
+    const int64_t gmax = (int64_t)ctx->cu_count * 2;
+    const int grid = (int)(npass < gmax ? npass : gmax);
+    switch (M.hid) {
+        case 128: return launch_jvp<128>(ctx, M.args, in, N, yout, J, grid, cv.total);
+        case 256: return launch_jvp<256>(ctx, M.args, in, N, yout, J, grid, cv.total);
+        case 512: return launch_jvp<512>(ctx, M.args, in, N, yout, J, grid, cv.total);
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
 }
@@ -1084,6 +1192,30 @@ int rt_mlp_forward(rt_ctx* ctx, int which, const float* in, int64_t N, float* ou
     rc = fwd_enqueue(ctx, which, (const float*)ctx->b_in.p, N, (float*)ctx->b_fout.p);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_fout.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_mlp_jacobian(rt_ctx* ctx, int which, const float* in, int64_t N, float* out, float* J) {
+    if (!ctx) return RT_EINVAL;
+    if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
+    HostMlp& M = ctx->mlp[which];
+    if (!M.set) return fail(ctx, RT_ENOTSET, "MLP has not been set");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N == 0) return RT_OK;
+    if (!in || !J) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t id = M.args.in_dim, od = M.args.out_dim;
+    const size_t ib = (size_t)N * id * sizeof(float), ob = (size_t)N * od * sizeof(float), jb = ob * id;
+    int rc = ensure(ctx, ctx->b_in, ib); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_fout, ob + jb); if (rc) return rc;
+    float* d_out = (float*)ctx->b_fout.p;
+    float* d_J = d_out + (size_t)N * od;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_in.p, in, ib, hipMemcpyHostToDevice, ctx->stream));
+    rc = jvp_enqueue(ctx, which, (const float*)ctx->b_in.p, N, d_out, d_J);
+    if (rc) return rc;
+    if (out) HIPCHK(ctx, hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(J, d_J, jb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }

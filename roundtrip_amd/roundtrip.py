@@ -83,6 +83,49 @@ class _IsModelBase(object):
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
 
+    # ---- the Laplace (closed-form) estimator ----------------------------------------------------------
+    def _jacobian(self, latent):
+        """(G(x) (N, y_dim), J (N, y_dim, x_dim)) as float64 containers of float32 values, like predict_y
+        (main_density_est.py:225) and get_jacobian (:254).  Forward-mode differentiation on the GPU."""
+        self._sync_weights()
+        out, J = self.engine.mlp_jacobian(_lib.RT_MLP_G, np.ascontiguousarray(latent, dtype=np.float32))
+        return out.astype(np.float64), J.astype(np.float64)
+
+    def _estimate_cf(self, points, sd, log):
+        """main_density_est.py:351-387 (v2: roundtrip.py:327-369).  The three network evaluations — H(y),
+        G(H(y)) and the Jacobian of G at H(y) — run on the GPU; the x_dim x x_dim linear algebra is the
+        reference's float64 numpy, batched over the points instead of mapped one by one."""
+        g_net = self._nets()[0][1]
+        points = np.asarray(points)
+        assert points.ndim == 2 and points.shape[-1] == g_net.output_dim
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        self._sync_weights()
+        eng = self.engine
+        x_dim, y_dim = g_net.input_dim, g_net.output_dim
+
+        def block(pts, base):
+            x_ = eng.mlp_forward(_lib.RT_MLP_H, pts.astype(np.float32)).astype(np.float64)          # :363
+            y__, jacob_mat = self._jacobian(x_)                                                      # :364, :367
+            resid = pts - y__
+            rt_error = np.sum(resid ** 2, axis=1)                                                    # :365
+            A = np.einsum('nij,nik->njk', jacob_mat, jacob_mat)                                      # :371
+            b = np.einsum('nij,ni->nj', jacob_mat, resid)                                            # :373
+            Sigma_inv = np.eye(x_dim)[None, :, :] + A / sd ** 2                                      # :376
+            Sigma = np.linalg.inv(Sigma_inv)                                                         # :375
+            mu = np.einsum('njk,nk->nj', Sigma, b / sd ** 2 - x_)                                    # :378
+            c_y = np.sum(x_ ** 2, axis=1) + rt_error / sd ** 2 - np.einsum('nj,njk,nk->n', mu, Sigma_inv, mu)  # :380
+            det = np.linalg.det(Sigma)
+            if log:
+                return -y_dim * np.log(np.sqrt(2 * np.pi) * sd) + 0.5 * np.log(det) - 0.5 * c_y      # :382
+            # :384 — the reference's log=False branch carries an extra sd**y_dim factor; kept as written
+            return 1. / (np.sqrt(2 * np.pi) * sd) ** y_dim * sd ** y_dim * np.sqrt(det) * np.exp(-0.5 * c_y)
+
+        if self.shard and dist.world()[1] > 1:
+            return dist.sharded_map(points, block)
+        if points.shape[0] == 0:
+            return np.zeros(0, dtype=np.float64)
+        return block(points, 0)
+
     def _estimate_is_multi(self, points, sds, scale, sample_size, df, log):
         """(len(sds), N): the estimate for several sd values from ONE sampler + G pass (same draws, as in the
         reference, which reseeds with 0 before every call)."""
@@ -158,6 +201,18 @@ class Roundtrip(_IsModelBase):
         x_points = np.asarray(x_points)
         assert x_points.shape[-1] == self.params['x_dim']
         return self._estimate_is(x_points, sd_x, scale, sample_size, df, log)
+
+    def get_jacobian(self, data_z):
+        """Batch Jacobian of g_net at data_z, shape [batch_size, x_dim, z_dim] (roundtrip.py:312-324)."""
+        data_z = np.asarray(data_z)
+        assert data_z.shape[-1] == self.params['z_dim']
+        return self._jacobian(data_z)[1].astype(np.float32)
+
+    def estimate_px_with_CF(self, x_points, sd_x=0.5, log=True):
+        """p(x) by the Laplace approximation (closed form), roundtrip.py:327-369."""
+        x_points = np.asarray(x_points)
+        assert x_points.shape[-1] == self.params['x_dim']
+        return self._estimate_cf(x_points, sd_x, log)
 
     def estimate_py_with_IS(self, y_points, epoch=0, sd_y=0.5, scale=0.5, sample_size=40000, bs=1024, log=True,
                             save=True, df=1):
@@ -240,6 +295,29 @@ class RoundtripModel(_IsModelBase):
                 os.makedirs(self.save_dir)
             np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
         return py_est
+
+    def get_jacobian(self, x, bs=16):
+        """(N, y_dim, x_dim) Jacobian of G (main_density_est.py:252-263); `bs` only batches the reference."""
+        x = np.asarray(x)
+        assert x.shape[-1] == self.x_dim
+        return self._jacobian(x)[1]
+
+    def estimate_py_with_CF(self, y_points, epoch, sd_y=0.5, log=True, save=True):
+        """p(y) by the Laplace approximation (closed form), main_density_est.py:351-387."""
+        y_points = np.asarray(y_points)
+        assert y_points.shape[-1] == self.y_dim
+        py_est = self._estimate_cf(y_points, sd_y, log)
+        if save:
+            if not os.path.exists(self.save_dir):
+                os.makedirs(self.save_dir)
+            np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
+        return py_est
+
+    def estimate_px_with_CF(self, x_points, sd_x=0.5, log=True):
+        """v2 spelling on the v1 object."""
+        x_points = np.asarray(x_points)
+        assert x_points.shape[-1] == self.y_dim
+        return self._estimate_cf(x_points, sd_x, log)
 
     def model_selection(self, sample_size=20000):
         """main_density_est.py:207-219: picks (sd, scale) maximising the mean validation log-likelihood over

@@ -100,3 +100,75 @@ def test_v1_model_selection_and_likelihood_summary(tmp_path, monkeypatch):
     est = m.estimate_py_with_IS(Sampler.X_val, 4, sd_y=best_sd, scale=best_scale, sample_size=S, save=False)
     assert mean == np.mean(est) and se == np.std(est) / np.sqrt(len(est))
     assert open("log_val.txt").read() == "%d\t%f\t%f\n" % (4, mean, se)
+
+
+def _cf_from_jacobian(y, x_, y__, J, sd, log):
+    """The reference's closed form (main_density_est.py:365-384), point by point, from given network outputs."""
+    dx, dy = x_.shape[1], y.shape[1]
+    out = []
+    for n in range(len(y)):
+        r = y[n] - y__[n]
+        A = J[n].T @ J[n]
+        b = J[n].T @ r
+        Si = np.eye(dx) + A / sd ** 2
+        Sg = np.linalg.inv(Si)
+        mu = Sg.dot(b / sd ** 2 - x_[n])
+        c = np.sum(x_[n] ** 2) + np.sum(r ** 2) / sd ** 2 - mu.T.dot(Si).dot(mu)
+        if log:
+            out.append(-dy * np.log(np.sqrt(2 * np.pi) * sd) + 0.5 * np.log(np.linalg.det(Sg)) - 0.5 * c)
+        else:
+            out.append(1. / (np.sqrt(2 * np.pi) * sd) ** dy * sd ** dy * np.sqrt(np.linalg.det(Sg)) * np.exp(-0.5 * c))
+    return np.array(out)
+
+
+def test_v1_estimate_py_with_CF(tmp_path, monkeypatch):
+    """estimate_py_with_CF / get_jacobian (main_density_est.py:252-263, 351-387) on the v1 object."""
+    from oracle import is_ref
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(1234)
+    g = Generator(3, 6, "g_net", nb_layers=10, nb_units=512, rng=rng)
+    h = Generator(6, 3, "h_net", nb_layers=10, nb_units=256, rng=rng)
+    m = RoundtripModel(g, h, None, None, None, None, "arem", None, 64, 10.0, 10.0, 1, False)
+    y = np.random.RandomState(42).standard_normal((37, 6)) * 0.3
+    sd = 0.5
+    got = m.estimate_py_with_CF(y, 2, sd_y=sd, log=True, save=True)
+    assert got.shape == (37,) and got.dtype == np.float64
+    assert np.array_equal(np.load("%s/py_est_at_epoch2.npy" % m.save_dir), got)
+    # same network outputs (kernel-order oracle) through the reference's formulas, point by point
+    og, oh = c_oracle.OracleMlp(g.weights, g.biases), c_oracle.OracleMlp(h.weights, h.biases)
+    x_ = oh.forward(y.astype(np.float32), c_oracle.ORDER_KERNEL).astype(np.float64)
+    y__, J = og.jacobian(x_, c_oracle.ORDER_KERNEL, nthreads=8)
+    np.testing.assert_allclose(got, _cf_from_jacobian(y, x_, y__.astype(np.float64), J.astype(np.float64), sd, True),
+                               rtol=1e-10)
+    jac = m.get_jacobian(x_)
+    assert jac.shape == (37, 6, 3) and np.array_equal(jac, J.astype(np.float64))
+    # the numpy restatement of the whole estimator (natural summation order): north_star tolerance 1e-4
+    want = is_ref.estimate_py_with_CF(is_ref.DenseNet(g.weights, g.biases), is_ref.DenseNet(h.weights, h.biases),
+                                      y, sd_y=sd, log=True)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    lin = m.estimate_py_with_CF(y, 2, sd_y=sd, log=False, save=False)
+    np.testing.assert_allclose(np.log(lin) - 6 * np.log(sd), got, rtol=1e-9)       # the reference's extra sd^dy
+    assert np.array_equal(m.estimate_px_with_CF(y, sd_x=sd), got)
+    assert m.estimate_py_with_CF(np.zeros((0, 6)), 0, save=False).shape == (0,)
+
+
+@pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
+def test_cf_golden_vectors(name, tmp_path):
+    from test_oracle import GOLDEN, golden_nets
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    f = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gw, gb, hw, hb = golden_nets(f)
+    dx, dy = int(f["dx"]), int(f["dy"])
+    params = dict(dataset=name, output_dir=str(tmp_path), x_dim=dy, z_dim=dx, g_units=[512] * 10, e_units=[256] * 10,
+                  save_model=False)
+    m = Roundtrip(params, timestamp="cf")
+    m.g_net.set_weights(gw, gb)
+    m.e_net.set_weights(hw, hb)
+    got = m.estimate_px_with_CF(f["y"], sd_x=float(f["sd"]), log=True)
+    np.testing.assert_allclose(got, f["cf_log_est"], rtol=1e-4)
+    jac = m.get_jacobian(f["xhat"])
+    assert jac.shape == (len(f["y"]), dy, dx) and jac.dtype == np.float32
+    assert np.abs(jac - f["jac_at_xhat"]).max() <= 1e-5 * np.abs(f["jac_at_xhat"]).max()

@@ -343,3 +343,55 @@ def test_multi_sd_shares_one_generator_pass(engine, make_nets):
         engine.is_estimate_multi(y, xhat, S, [0.1] * 9, 0.1)
     with pytest.raises(_lib.RtError):
         engine.is_estimate_multi(y, xhat, S, [0.1, -1.0], 0.1)
+
+
+@pytest.mark.parametrize("dx,dy", DIMS)
+def test_jacobian_bit_exact(engine, make_nets, dx, dy):
+    """rt_mlp_jacobian (get_jacobian, main_density_est.py:252-263) == the C oracle's forward-mode Jacobian in kernel
+    order, bit for bit, for ragged row counts around the 32-row pass; close to the natural-order / numpy oracles."""
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og, oh = c_oracle.OracleMlp(gw, gb), c_oracle.OracleMlp(hw, hb)
+    rng = np.random.RandomState(dx * 7 + dy)
+    for n in (1, 31, 32, 33, 70):
+        x = rng.standard_normal((n, dx)).astype(np.float32)
+        out, J = engine.mlp_jacobian(G, x)
+        assert J.shape == (n, dy, dx)
+        wout, wJ = og.jacobian(x, c_oracle.ORDER_KERNEL, nthreads=8)
+        assert np.array_equal(out, wout)
+        assert np.array_equal(J, wJ)
+        assert np.array_equal(out, engine.mlp_forward(G, x))
+    nat = is_ref.get_jacobian(is_ref.DenseNet(gw, gb), x)
+    assert np.abs(J - nat).max() <= 1e-5 * np.abs(nat).max()
+    y = rng.standard_normal((40, dy)).astype(np.float32)
+    out, J = engine.mlp_jacobian(H, y)
+    wout, wJ = oh.jacobian(y, c_oracle.ORDER_KERNEL, nthreads=8)
+    assert np.array_equal(out, wout) and np.array_equal(J, wJ)
+    assert engine.mlp_jacobian(G, np.zeros((0, dx), np.float32))[1].shape == (0, dy, dx)
+
+
+def test_jacobian_other_widths_and_limits(engine):
+    from conftest import glorot
+    for dims in ([4, 128, 128, 3], [2, 100, 200, 7], [3, 256, 256, 256, 2]):
+        ws, bs = glorot(dims, 41, 42)
+        engine.set_mlp(G, ws, bs)
+        x = np.random.RandomState(1).standard_normal((45, dims[0])).astype(np.float32)
+        out, J = engine.mlp_jacobian(G, x)
+        nat_out, nat_J = c_oracle.OracleMlp(ws, bs).jacobian(x, c_oracle.ORDER_NATURAL, nthreads=8)
+        assert np.abs(out - nat_out).max() <= 4e-6 * np.abs(nat_out).max()
+        assert np.abs(J - nat_J).max() <= 1e-5 * np.abs(nat_J).max()
+    ws, bs = glorot([2, 1024, 1024, 2], 43, 44)
+    engine.set_mlp(G, ws, bs)
+    with pytest.raises(_lib.RtError):          # 32-row passes (width 1024) cannot pair primal and tangent tiles
+        engine.mlp_jacobian(G, np.zeros((3, 2), np.float32))
+
+
+@pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
+def test_jacobian_golden(engine, name):
+    f = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gw, gb, hw, hb = golden_nets(f)
+    engine.set_mlp(G, gw, gb)
+    out, J = engine.mlp_jacobian(G, f["xhat"])
+    np.testing.assert_allclose(out, f["g_of_xhat"], rtol=2e-5, atol=1e-7)
+    assert np.abs(J - f["jac_at_xhat"]).max() <= 1e-5 * np.abs(f["jac_at_xhat"]).max()

@@ -202,3 +202,58 @@ def test_oracle_sampler_statistics():
     assert np.array_equal(xs.astype(np.float32), c_oracle.draw_samples(xhat, 0, 20000, 0.5, 1.0, seed=0)[0])
     assert not np.array_equal(xs.astype(np.float32), c_oracle.draw_samples(xhat, 1, 20000, 0.5, 1.0, seed=0)[0])
     assert not np.array_equal(xs.astype(np.float32), c_oracle.draw_samples(xhat, 0, 20000, 0.5, 1.0, seed=1)[0])
+
+
+def test_jacobian_restatements_agree_and_match_finite_differences():
+    """get_jacobian (main_density_est.py:252-263) restated twice: numpy float32 forward mode (is_ref) and the C
+    oracle in both summation orders; all agree with float64 central differences of the same MLP."""
+    ws, bs = glorot([3, 128, 128, 128, 5], 31, 32)
+    net = is_ref.DenseNet(ws, bs)
+    om = c_oracle.OracleMlp(ws, bs)
+    x = np.random.RandomState(8).standard_normal((9, 3)).astype(np.float32)
+    J = is_ref.get_jacobian(net, x)
+    assert J.shape == (9, 5, 3) and J.dtype == np.float64
+    for order in (c_oracle.ORDER_NATURAL, c_oracle.ORDER_KERNEL):
+        out, Jc = om.jacobian(x, order, nthreads=4)
+        assert np.array_equal(out, om.forward(x, order))
+        assert np.abs(Jc - J).max() <= 2e-6 * np.abs(J).max()
+
+    def f64(xx):
+        h = xx.astype(np.float64)
+        for l, (w, b) in enumerate(zip(ws, bs)):
+            h = h @ w.astype(np.float64) + b
+            if l < len(ws) - 1:
+                h = np.maximum(h, 0.2 * h)
+        return h
+    eps = 1e-6
+    fd = np.stack([(f64(x + eps * np.eye(3)[d]) - f64(x - eps * np.eye(3)[d])) / (2 * eps) for d in range(3)], axis=2)
+    assert np.abs(fd - J).max() <= 1e-5 * np.abs(J).max()
+
+
+def test_cf_linear_generator_known_answer():
+    """With G(x) = x A + b the Laplace approximation is exact whatever point it expands at, so
+    estimate_py_with_CF (main_density_est.py:351-387) must give log N(y; b, A^T A + sd^2 I); the log=False branch
+    carries the reference's extra sd^dy factor (:384)."""
+    dx, dy, sd = 2, 3, 0.4
+    A = np.array([[1.0, 0.5, -0.25], [0.3, -0.7, 0.9]], np.float32)
+    b = np.array([0.1, -0.2, 0.3], np.float32)
+    g = is_ref.DenseNet(*linear_g(dx, dy, 128, 3, A, b))
+    h = is_ref.DenseNet(*glorot([dy, 128, 128, dx], 17, 18))      # any encoder: the expansion point is arbitrary
+    ys = np.random.RandomState(2).standard_normal((6, dy))
+    cov = A.T.astype(np.float64) @ A + sd * sd * np.eye(dy)
+    want = np.array([gaussian_logpdf(y, b.astype(np.float64), cov) for y in ys])
+    got = is_ref.estimate_py_with_CF(g, h, ys, sd_y=sd, log=True)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    lin = is_ref.estimate_py_with_CF(g, h, ys, sd_y=sd, log=False)
+    np.testing.assert_allclose(np.log(lin) - dy * np.log(sd), want, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
+def test_cf_golden_is_reproducible(name):
+    """The committed Laplace-estimator goldens come from is_ref.estimate_py_with_CF (oracle/make_golden.py)."""
+    f = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gw, gb, hw, hb = golden_nets(f)
+    g, h = is_ref.DenseNet(gw, gb), is_ref.DenseNet(hw, hb)
+    np.testing.assert_allclose(is_ref.get_jacobian(g, f["xhat"]), f["jac_at_xhat"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(is_ref.estimate_py_with_CF(g, h, f["y"], sd_y=float(f["sd"]), log=True),
+                               f["cf_log_est"], rtol=1e-6)
