@@ -66,6 +66,25 @@ def cpu_baseline(g, h, y, S, sd, scale, n_points, eng):
             "seconds": dt}
 
 
+def measured_traffic(grid, S, dx, dy):
+    """HBM-side bytes per launch of the fused kernel for THIS workload, from the committed PMC passes
+    (profiles/r*_pmc_v*.json, written by scripts/pmc.sh + scripts/pmc_profile.py: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc runs, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read from
+    inside an unprofiled run, so the figure is the recorded one; None if no recorded pass matches the workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_v*.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        k = d.get("bench_key", {})
+        if (k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy")) == (grid, S, dx, dy) \
+                and "traffic_bytes_per_launch" in d:
+            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +165,7 @@ def main():
         evals = float(n_total) * S * args.steps
         res = (gathered if world > 1 else out_dev).cpu().numpy()
         achieved = ctr["flops"] / (ctr["kernel_ms"] * 1e-3) / 1e12 if ctr["kernel_ms"] > 0 else 0.0
+        traffic = measured_traffic(args.grid, S, dx, dy)
         line = {
             "metric": "IS sample-evals/sec (N_y x S through G)",
             "value": evals / elapsed,
@@ -164,8 +184,10 @@ def main():
                                    "Glorot RandomState(1234)" % (args.grid, args.grid, S),
                        "query_points_total": int(n_total), "sample_size": S, "parallelism": "y-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "is_fused_kernel<512,false>",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": traffic[0] if traffic else None, "traffic_unit": "bytes/launch",
+                         "traffic_source": ("PMC passes recorded in profiles/%s" % traffic[1]) if traffic else None,
+                         "kernel": "is_fused_kernel<512,2,false>",
                          "kernel_ms_avg": ctr["kernel_ms"] / max(1, ctr["launches"]),
                          "launches": ctr["launches"],
                          "flops_per_sample_eval": ctr["flops"] / max(1, ctr["sample_evals"])},
