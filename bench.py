@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="grid side; query points per GPU = grid^2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=32)
+    # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never used by the driver):
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo gathers through host tensors (rehearsal only)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,17 +109,22 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     import torch
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    host_gather = args.backend == "gloo"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if host_gather:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from roundtrip_amd import _lib, dist as rdist
     dx = dy = 2
     S, sd, scale = args.sample_size, 0.1, 0.5
     g, h = build_nets(dx, dy)
-    eng = _lib.Engine(local_rank)
+    eng = _lib.Engine(dev_index)
     eng.set_mlp(_lib.RT_MLP_G, g.weights, g.biases, g.alpha)
     eng.set_mlp(_lib.RT_MLP_H, h.weights, h.biases, h.alpha)
 
@@ -127,7 +136,8 @@ def main():
     y32_dev = y_dev.to(torch.float32)                                             # H's float32 feed
     xhat_dev = torch.empty((hi - lo, dx), dtype=torch.float32, device=dev)
     out_dev = torch.zeros(per_gpu, dtype=torch.float64, device=dev)
-    gathered = torch.empty(per_gpu * world, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = (torch.empty(per_gpu * world, dtype=torch.float64, device="cpu" if host_gather else dev)
+                if world > 1 else None)
     torch.cuda.synchronize()
 
     def step():
@@ -136,7 +146,7 @@ def main():
                             df=1.0, seed=0, log=False, y_index_base=lo)
         if world > 1:
             eng.sync()   # results are produced on the engine's stream; the gather runs on torch's
-            dist.all_gather_into_tensor(gathered, out_dev)
+            dist.all_gather_into_tensor(gathered, out_dev.cpu() if host_gather else out_dev)
 
     def fence():
         eng.sync()
@@ -156,7 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctr = eng.counters()
