@@ -89,17 +89,29 @@ static int k_sequence(const rto_mlp* m, int l, int order, int* seq, int* qstart,
         qstart[0] = 0; qstart[1] = n; *nq_out = 1;
         return n;
     }
+    /* the kernel runs at the hidden width padded up to 128/256/512/1024: its K-quarters are quarters of THAT */
+    int hmax = 0;
+    for (int i = 1; i < m->n_layers; ++i) if (m->dims[i] > hmax) hmax = m->dims[i];
+    const int hid = hmax <= 128 ? 128 : hmax <= 256 ? 256 : hmax <= 512 ? 512 : 1024;
     const int ngrp = (K + 7) / 8;
     const int nq = (last && m->n_layers > 1) ? 4 : 1;
-    const int gq = (ngrp + nq - 1) / nq; /* groups per quarter (K is a multiple of 32 there) */
+    const int gq = (nq == 4) ? hid / 32 : ngrp; /* groups per quarter */
+    /* output layers of width <= 4 run on 4x4x1 MFMAs (rt_is.hip last_layer_small; 64-sample passes, i.e. hidden
+     * width <= 512): k ascends inside a quarter */
+    const int small = last && nq == 4 && m->dims[l + 1] <= 4 && hid <= 512;
     for (int q = 0; q < nq; ++q) {
         qstart[q] = n;
-        for (int g = q * gq; g < (q + 1) * gq && g < ngrp; ++g)
+        for (int g = q * gq; g < (q + 1) * gq && g < ngrp; ++g) {
+            if (small) {
+                for (int k = 8 * g; k < 8 * g + 8; ++k) if (k < K) seq[n++] = k;
+                continue;
+            }
             for (int e = 0; e < 4; ++e)
                 for (int hh = 0; hh < 2; ++hh) {
                     const int k = 8 * g + 4 * hh + e;
                     if (k < K) seq[n++] = k; /* zero padding: fmaf(0, 0, acc) == acc */
                 }
+        }
     }
     qstart[nq] = n;
     *nq_out = nq;

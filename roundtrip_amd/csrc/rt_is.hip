@@ -43,6 +43,7 @@ constexpr int MAX_OUT = 128;    // max output dim of a fused MLP (dy for G)
 struct MlpArgs {
     const float* wp[RT_MAX_LAYERS];  // packed weights, see pack_layer()
     const float* bp[RT_MAX_LAYERS];  // biases padded to a multiple of 32
+    const float* wsmall;             // output layer for out_dim <= 4 (see last_layer_small), else nullptr
     int n_layers;
     int in_dim;
     int out_dim;
@@ -392,6 +393,42 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
     __syncthreads();
 }
 
+// Output layer when out_dim <= 4 (the 2-D sets: dy = 2; H for dx <= 4), 64-sample passes only.  A 32x32 tile
+// would be 7/8 padding there (8192 cycles per pass and wave, 0.8 % of the bench workload).  v_mfma_f32_4x4x1_16B_f32
+// runs 16 independent 4x4 blocks: block b = lanes 4b..4b+3, A_b[i][k] from lane 4b+i, B_b[k][j] from lane 4b+j,
+// D_b[i][j] in register i of lane 4b+j.  With A_b[i] = W[k][i] for every block and B_b[j] = act[k][sample 4b+j], lane s
+// ends with the four output features of sample s.  K is split over the waves like in last_layer; inside a quarter
+// k ascends.  wsmall[((kg*2 + hh)*4 + i)*4 + e] = W[8kg + 4hh + e][i] (zero for i >= out_dim).
+// small_load_w requests this wave's K-quarter of the weights (they do not depend on the activations: it is called
+// before the barrier that publishes the last hidden layer, so the L2 round trip hides behind it).
+template <int KQ>
+__device__ __forceinline__ void small_load_w(const MlpArgs& m, int wave, int lane, f32x4 (&w)[2 * KQ]) {
+    const f32x4* wp = (const f32x4*)m.wsmall + (size_t)(wave * KQ) * 8 + (lane & 3);
+#pragma unroll
+    for (int i = 0; i < 2 * KQ; ++i) w[i] = wp[i * 4];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int KQ>
+__device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (&w)[2 * KQ], char* act, float* part,
+                                                 int wave, int lane) {
+    constexpr int MS = 64;
+    f32x4 b[2 * KQ];
+#pragma unroll
+    for (int i = 0; i < 2 * KQ; ++i) b[i] = *(const f32x4*)(act + act_off<MS>(wave * KQ + (i >> 1), lane, i & 1));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2 * KQ; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i][e], b[i][e], acc, 0, 0, 0);
+    __syncthreads();   // every wave is done reading the activation image
+    const int od = m.out_dim;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (d < od) part[(wave * od + d) * MS + lane] = acc[d];
+    __syncthreads();
+}
+
 // Runs the MLP on the MS samples whose (padded) inputs sit in the x0 image.  On return
 // part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 256 threads.
@@ -409,21 +446,37 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     ST(1)
     const int nhid = m.n_layers - 1;
     f32x4 a0[NFT], a1[NFT], a2[NFT];
-    for (int l = 0; l < nhid; ++l) {
+    constexpr int KQ = HID / 32;        // k-groups per wave in the output layer
+    const bool small_out = (NST == 2) && m.wsmall != nullptr;
+    for (int l = 0; l + 1 < nhid; ++l) {
         const WSrc wnext = make_wsrc(m.wp[l + 1] + (wave * NFT) * 256, lane);
-        if (l + 1 < nhid) prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
+        prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
         store_act<NFT, NST, JVP>(acc, m.alpha, act, wave, lane);
-        if (l + 1 < nhid) load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
+        load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
         ST(3)
         __syncthreads();
         ST(4)
-        if (l + 1 < nhid)
-            gemm_tile<NFT, NST, JVP>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
+        gemm_tile<NFT, NST, JVP>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
         ST(5)
     }
+    // the last hidden layer's epilogue (kept out of the loop so the output layer's prefetched weights are not live
+    // across the hidden layers' K loops)
+    f32x4 wsm[2 * KQ];
+    if (nhid > 1) __syncthreads();
+    ST(2)
+    store_act<NFT, NST, JVP>(acc, m.alpha, act, wave, lane);
+    if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
+    ST(3)
+    __syncthreads();
+    ST(4)
     float* part = (float*)act;
+    if (small_out) {
+        last_layer_small<KQ>(m, wsm, act, part, wave, lane);
+        ST(6)
+        return;
+    }
     switch (m.nt_out) {
         case 1: last_layer<1, NST>(m, HID / 32, act, part, wave, lane); break;
         case 2: last_layer<2, NST>(m, HID / 32, act, part, wave, lane); break;
@@ -1164,6 +1217,19 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
         HIPCHK(ctx, hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
         M.args.wp[l] = (const float*)dw;
         M.args.bp[l] = (const float*)db;
+    }
+    if (nst == 2 && dims[n_layers] <= 4) {
+        // output layer in last_layer_small's order: wsmall[((kg*2 + hh)*4 + i)*4 + e] = W[8kg + 4hh + e][i]
+        const int l = n_layers - 1, K = dims[l], NF = dims[l + 1];
+        std::vector<float> ws((size_t)hid * 4, 0.0f);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < NF; ++i)
+                ws[(size_t)(((k >> 3) * 2 + ((k >> 2) & 1)) * 4 + i) * 4 + (k & 3)] = W[l][(size_t)k * NF + i];
+        void* dws = nullptr;
+        HIPCHK(ctx, hipMalloc(&dws, ws.size() * sizeof(float)));
+        M.dev.push_back(dws);
+        HIPCHK(ctx, hipMemcpy(dws, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+        M.args.wsmall = (const float*)dws;
     }
     M.set = true;
     return RT_OK;
