@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--sample-size", type=int, default=10000)
     ap.add_argument("--grid", type=int, default=100, help="grid side; query points per GPU = grid^2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-points", type=int, default=32)
+    ap.add_argument("--cpu-points", type=int, default=160,
+                    help="query points of the cpu_baseline sample (160 x S=10000 is about 13 s on 16 host cores)")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never used by the driver):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo gathers through host tensors (rehearsal only)")

@@ -85,6 +85,25 @@ __device__ __forceinline__ int act_off(int kg, int s, int hh) {
 // MFMA 32x32x2 operand maps (cdna_hip_programming.md §3): lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // here lane half h at step e handles k = 8kg + 4h + e (any k order is a valid sum).
 // ----------------------------------------------------------------------------------------------
+// One v_max_f32.  fmaxf() on a value that comes straight out of an MFMA makes hipcc put a canonicalising
+// v_max in front of it (128 extra instructions per epilogue); the bare instruction has fmaxf's NaN behaviour.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// lrelu of accumulator registers [4q, 4q+4) of one tile, in place: max(t, alpha*t), two elements per v_pk_mul_f32.
+__device__ __forceinline__ void lrelu_quad(f32x16& t, int q, float alpha) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const f32x2 v = f32x2{t[4 * q + e], t[4 * q + e + 1]};
+        const f32x2 u = v * f32x2{alpha, alpha};
+        t[4 * q + e] = vmax(v[0], u[0]);
+        t[4 * q + e + 1] = vmax(v[1], u[1]);
+    }
+}
+
 // FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
 // JVP: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.
@@ -103,67 +122,38 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
                     (FIRST && e == 0) ? ((cinit && !(JVP && st == 1)) ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
 }
 
-// acc[ft][st] += sum over kg in [0, nkg) of W-slice · activations.
-//   wl   : this lane's packed A operands for (kg = first, ft = 0); stride between kg = ftt*64 f32x4,
-//          between feature tiles = 64 f32x4
-//   bl   : LDS byte address of this lane's B operand for (kg = first, sample tile 0); kg stride 64*NST*16 B,
-//          sample tile stride 1024 B
-#ifndef RT_BUFLOAD
-#define RT_BUFLOAD 1   // 1: weights by buffer_load (SGPR descriptor + scalar k-group offset, no per-lane address math)
-#endif
-// Source of one wave's packed weights for a layer.
+// Source of one wave's packed weights for a layer: a buffer resource (SGPR descriptor) plus the lane's byte offset, so
+// the k-group offset is a scalar and the loads need no per-lane address arithmetic.
 struct WSrc {
-#if RT_BUFLOAD
     __amdgpu_buffer_rsrc_t r;
     int voff;            // lane * 16
-#else
-    const f32x4* p;      // base + lane
-#endif
 };
 // base must be wave-uniform (kernel argument + wave index from readfirstlane).
 __device__ __forceinline__ WSrc make_wsrc(const float* base, int lane) {
     WSrc w;
-#if RT_BUFLOAD
     w.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     w.voff = lane * 16;
-#else
-    w.p = (const f32x4*)base + lane;
-#endif
     return w;
 }
 // A operands of (k-group kg, feature tile ft); wstride = f32x4 elements between k-groups.
 __device__ __forceinline__ f32x4 wload(const WSrc& w, int kg, int wstride, int ft) {
-#if RT_BUFLOAD
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, w.voff + ft * 1024, kg * wstride * 16, 0);
     return __builtin_bit_cast(f32x4, v);
-#else
-    return w.p[(size_t)kg * wstride + ft * 64];
-#endif
 }
 
-#ifndef RT_SCHED
-#define RT_SCHED 0   // placement of the K loop's memory instructions among the MFMAs (see pipe_stage)
-#endif
-#ifndef RT_ABL
-#define RT_ABL 0   // diagnostic ablations (never set in the shipped build): 1 = no weight loads, 2 = no LDS reads in the K loop
-#endif
-template <int NFT, int NST, int ABL = 0>
+// Operands of k-group kg.
+//   wl   : this wave's packed A operands (stride between k-groups = wstride f32x4, between feature tiles = 64 f32x4)
+//   bl   : LDS byte address of this lane's B operand for (kg = 0, sample tile 0); kg stride 64*NST*16 B,
+//          sample tile stride 1024 B
+template <int NFT, int NST>
 __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], const WSrc& wl,
                                            int wstride, const char* bl, int kg) {
     const char* l = bl + kg * (1024 * NST);
-    if (!(ABL & 1)) {
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) a[ft] = wload(wl, kg, wstride, ft);
-    } else {
+    for (int ft = 0; ft < NFT; ++ft) a[ft] = wload(wl, kg, wstride, ft);
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) asm volatile("" : "+v"(a[ft]));
-    }
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        if (!(ABL & 2)) b[st] = *(const f32x4*)(l + 1024 * st);
-        else asm volatile("" : "+v"(b[st]));
-    }
+    for (int st = 0; st < NST; ++st) b[st] = *(const f32x4*)(l + 1024 * st);
 }
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
@@ -189,10 +179,9 @@ __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
                                            const WSrc& wl, int wstride, const char* bl, int kgn,
                                            const f32x16* cinit = nullptr) {
-    load_group<NFT, NST, RT_ABL>(an, bn, wl, wstride, bl, kgn);
+    load_group<NFT, NST>(an, bn, wl, wstride, bl, kgn);
     mfma_group<NFT, NST, FIRST, JVP>(acc, ac, bc, cinit);
     constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
-#if RT_SCHED == 0
 #pragma unroll
     for (int i = 0; i < NFT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -204,41 +193,6 @@ __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NFT - NST, 0);
-#elif RT_SCHED == 1   // memory instructions spread evenly over the stage
-    constexpr int GAP = NM / (NFT + NST);
-#pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NFT + NST), 0);
-#elif RT_SCHED == 2   // two memory instructions behind each of the first MFMAs
-#pragma unroll
-    for (int i = 0; i < NFT / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NST, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NM - NFT / 2 - 1, 0);
-#elif RT_SCHED == 3   // LDS reads first (short latency chain), weights later
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NST - 4 * NFT, 0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -259,10 +213,37 @@ __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f
 // nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
 // MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
 // a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
-template <int NFT, int NST, bool JVP = false>
+// Last k-group of a hidden layer (ACT0: 64-sample passes, not the Jacobian kernel).  Sample tile 0's MFMAs go first;
+// its leaky-ReLU (6 VALU instructions per MFMA) then issues in the shadow of sample tile 1's MFMAs, so half of the
+// epilogue's arithmetic costs no time.  Every accumulator still sees its k's in the same order.  The sched_barriers
+// keep hipcc from moving the VALU work behind the MFMAs again.
+template <int NFT, int NST>
+__device__ __forceinline__ void final_stage_act0(f32x16 (&acc)[NFT][NST], const f32x4 (&ac)[NFT],
+                                                 const f32x4 (&bc)[NST], float alpha) {
+    static_assert(NST == 2, "needs two sample tiles");
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft)
+            acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ft][e], bc[0][e], acc[ft][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ft][e], bc[1][e], acc[ft][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int idx = e * NFT + ft;            // 4*NFT chunks of one register quad each
+            lrelu_quad(acc[idx >> 2][0], idx & 3, alpha);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// ACT0: on return sample tile 0's accumulators already hold lrelu(pre-activation) (see final_stage_act0).
+template <int NFT, int NST, bool JVP = false, bool ACT0 = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
                                           f32x4 (&a2)[NFT], const WSrc& wl,
-                                          int ftt, int nkg, const char* bl, const f32x16* cinit) {
+                                          int ftt, int nkg, const char* bl, const f32x16* cinit, float alpha = 0.f) {
     f32x4 a3[NFT], b0[NST], b1[NST], b2[NST], b3[NST];
     const int wstride = ftt * 64;
     const int lastg = nkg - 1;
@@ -272,19 +253,35 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
         b1[st] = *(const f32x4*)(bl + 1024 * NST + 1024 * st);
         b2[st] = *(const f32x4*)(bl + 2048 * NST + 1024 * st);
     }
-    if (RT_ABL) load_group<NFT, NST>(a3, b3, wl, wstride, bl, 3);
     __builtin_amdgcn_sched_barrier(0);
     // first four k-groups peeled: their first MFMAs start the accumulators from the constant 0
     pipe_stage<NFT, NST, true, JVP>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
     pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(4, lastg));
     pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(5, lastg));
     pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(6, lastg));
+    if constexpr (!ACT0) {
 #pragma unroll 1
-    for (int kg = 4; kg < nkg; kg += 4) {
-        pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
-        pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
-        pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
-        pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(kg + 6, lastg));
+        for (int kg = 4; kg < nkg; kg += 4) {
+            pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
+            pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(kg + 4, lastg));
+            pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(kg + 5, lastg));
+            pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(kg + 6, lastg));
+        }
+    } else {
+        // nkg >= 8 here (hidden layers: nkg = HID/8 >= 16); the last four k-groups are peeled
+#pragma unroll 1
+        for (int kg = 4; kg < nkg - 4; kg += 4) {
+            pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, kg + 3);
+            pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, kg + 4);
+            pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, kg + 5);
+            pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, kg + 6);
+        }
+        pipe_stage<NFT, NST>(acc, a3, b3, a0, b0, wl, wstride, bl, lastg);
+        mfma_group<NFT, NST>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<NFT, NST>(acc, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        final_stage_act0<NFT, NST>(acc, a3, b3, alpha);
     }
 }
 
@@ -304,14 +301,6 @@ __device__ __forceinline__ void load_bias(f32x16 (&bv)[NFT], const float* __rest
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// One v_max_f32.  fmaxf() on a value that comes straight out of an MFMA makes hipcc put a canonicalising
-// v_max in front of it (128 extra instructions per epilogue); the bare instruction has fmaxf's NaN behaviour.
-__device__ __forceinline__ float vmax(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // Hidden-layer epilogue: act = lrelu(acc), written in the next layer's B-operand image.  The bias is already in
 // acc: the layer's first MFMA takes it as its C operand (mfma_group's cinit), so a feature's value is the fp32
 // fmaf chain  fma(w_kn, x_kn, ... fma(w_k0, x_k0, bias)).
@@ -320,7 +309,8 @@ __device__ __forceinline__ float vmax(float a, float b) {
 // JVP (NST == 2): tile 0 holds primal pre-activations t, tile 1 the tangent pre-activations dt of the SAME rows in
 // the same lanes and registers, so the tangent's activation is lrelu'(t) * dt with no cross-lane traffic:
 // slope 1 where t > 0, alpha elsewhere.
-template <int NFT, int NST, bool JVP = false>
+// ACT0: sample tile 0 is already activated (gemm_tile<..., ACT0>); only tile 1's arithmetic is left.
+template <int NFT, int NST, bool JVP = false, bool ACT0 = false>
 __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane) {
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
@@ -351,15 +341,9 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    // two lanes' worth per instruction: v_pk_add_f32 / v_pk_mul_f32 (same IEEE results)
-                    const f32x2 t = f32x2{acc[ft][st][4 * q + e], acc[ft][st][4 * q + e + 1]};
-                    const f32x2 u = t * f32x2{alpha, alpha};
-                    v[e] = vmax(t[0], u[0]);
-                    v[e + 1] = vmax(t[1], u[1]);
-                }
+                if (!(ACT0 && st == 0)) lrelu_quad(acc[ft][st], q, alpha);
+                const f32x4 v = {acc[ft][st][4 * q], acc[ft][st][4 * q + 1], acc[ft][st][4 * q + 2],
+                                 acc[ft][st][4 * q + 3]};
                 *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 * st + j, h)) = v;
             }
         }
@@ -443,6 +427,14 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     load_bias<NFT>(bv, m.bp[0], wave, lane);
     gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
                                     x0 + act_off<MS>(0, j, h), bv);
+    // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
+    constexpr bool ACT0 = (NST == 2) && !JVP;
+    if constexpr (ACT0) {
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lrelu_quad(acc[ft][0], q, m.alpha);
+    }
     ST(1)
     const int nhid = m.n_layers - 1;
     f32x4 a0[NFT], a1[NFT], a2[NFT];
@@ -453,12 +445,12 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
         prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
         if (l > 0) __syncthreads();   // all waves finished reading layer l's input
         ST(2)
-        store_act<NFT, NST, JVP>(acc, m.alpha, act, wave, lane);
+        store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
         load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
         ST(3)
         __syncthreads();
         ST(4)
-        gemm_tile<NFT, NST, JVP>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv);
+        gemm_tile<NFT, NST, JVP, ACT0>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv, m.alpha);
         ST(5)
     }
     // the last hidden layer's epilogue (kept out of the loop so the output layer's prefetched weights are not live
@@ -466,7 +458,7 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     f32x4 wsm[2 * KQ];
     if (nhid > 1) __syncthreads();
     ST(2)
-    store_act<NFT, NST, JVP>(acc, m.alpha, act, wave, lane);
+    store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
     if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
     ST(3)
     __syncthreads();

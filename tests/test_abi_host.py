@@ -296,3 +296,25 @@ def test_sharded_map_world_size_2_gloo(tmp_path, n):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("rank ok") == 2
+
+
+def test_evaluate_callers_host_logic():
+    """precision_at_K / create_2d_grid_data (evaluate.py:15-20, 55-59) and the callers' plumbing with a stub model."""
+    from roundtrip_amd import evaluate as ev
+    v1, v2, grid = ev.create_2d_grid_data(-5, 5, -5, 5, n=100)
+    assert grid.shape == (10000, 2) and grid[0].tolist() == [-5.0, -5.0] and grid[99].tolist() == [5.0, -5.0]
+    score = np.array([0.5, -3.0, 0.1, -2.5, 2.0, -0.2])          # lower = more abnormal
+    label = np.array([0, 1, 0, 0, 0, 1])                         # two outliers
+    assert ev.precision_at_K(score, label) == 0.5               # the two lowest are index 1 (outlier) and 3 (inlier)
+
+    class Stub(object):
+        def estimate_py_with_IS(self, y, epoch, sd_y=0.5, scale=0.5, sample_size=40000, bs=1024, log=True, save=True):
+            self.seen = dict(n=len(y), sd_y=sd_y, scale=scale, sample_size=sample_size, log=log, save=save)
+            return -np.sum(np.asarray(y) ** 2, axis=1) if log else np.exp(-np.sum(np.asarray(y) ** 2, axis=1))
+    m = Stub()
+    (rng, sd, sc) = ev.GRID_SETTINGS["eight_octagon_gmm"]
+    _, _, py = ev.visualization_2d(m, *rng, sd_y=sd, scale=sc, n=20)
+    assert py.shape == (20, 20) and m.seen == dict(n=400, sd_y=0.1, scale=0.5, sample_size=10000, log=False, save=False)
+    X = np.array([[0.0, 0.1], [3.0, 3.0], [0.2, 0.0], [-4.0, 1.0]])
+    prec, py = ev.odd_evaluate(m, X, np.array([0, 1, 0, 1]), 0.1, 0.5)
+    assert prec == 1.0 and m.seen["log"] is True
