@@ -350,6 +350,210 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Skewed hidden layers (64-sample passes; not the Jacobian kernel): the epilogue hides behind MFMAs.
+//
+// A layer's epilogue stores 128 KB of activations per CU through ds_write_b128 (~79 B/clk/CU): ~2700 cycles
+// during which, in the plain schedule (gemm_tile + store_act), no MFMA issues, because the image is updated in
+// place and cannot be double-buffered in 160 KB.  Here sample tile 1 ("B") runs SKEW = 2 k-groups behind sample
+// tile 0 ("A") inside the same K loop: a stage s issues A's MFMAs for k-group s and B's for k-group s-2, with the
+// weights of a k-group kept in registers two stages longer (ring of 6).  A layer is NKG + 2 stages:
+//   stages 0, 1        A only; the PREVIOUS layer's tile B is activated (stage 0) and stored (stage 1) in the
+//                      MFMAs' shadow; barrier (B's image is published) before stage 2
+//   stages 2 .. NKG-1  A and B
+//   stages NKG, NKG+1  B only; THIS layer's tile A is activated (stage NKG) and stored (stage NKG+1) in the
+//                      MFMAs' shadow; a barrier before the stores (every wave is done reading A's image),
+//                      one after them (A's image is published, every wave is done reading B's image)
+// Every accumulator sees its k's in the same order as in the plain schedule, so results are bit-identical.
+// Ring slots: weights of k-group g in w[g % 6]; A's operand of k-group g in bA[g % 6]; B's in bB[(g + 2) % 6];
+// all three are requested three stages before their first use.  Needs (NKG + 2) % 6 == 0: widths 128 and 512.
+// ----------------------------------------------------------------------------------------------
+template <int NFT>
+__device__ __forceinline__ void store_quad(const f32x16 (&t)[NFT][2], int st, int idx, char* st_base) {
+    const int ft = idx >> 2, q = idx & 3;
+    const f32x4 v = {t[ft][st][4 * q], t[ft][st][4 * q + 1], t[ft][st][4 * q + 2], t[ft][st][4 * q + 3]};
+    *(f32x4*)(st_base + (4 * ft + q) * 2048 + st * 1024) = v;
+}
+
+// The MFMAs of ring position R.  DO_A / DO_B: which tiles take part; FIRST_*: the tile's first k-group (C = bias).
+template <int NFT, int R, bool DO_A, bool DO_B, bool FIRST_A, bool FIRST_B>
+__device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&w)[6][NFT], const f32x4 (&bA)[6],
+                                           const f32x4 (&bB)[6], const f32x16 (&bv)[NFT]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            if (DO_A)
+                acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[R][ft][e], bA[R][e],
+                                                                  (FIRST_A && e == 0) ? bv[ft] : acc[ft][0], 0, 0, 0);
+            if (DO_B)
+                acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(R + 4) % 6][ft][e], bB[R][e],
+                                                                  (FIRST_B && e == 0) ? bv[ft] : acc[ft][1], 0, 0, 0);
+        }
+}
+
+// A steady stage s (ring position R = s % 6): requests the operands of three stages ahead, runs both tiles' MFMAs,
+// and pins one memory instruction behind each of the first MFMAs (see pipe_stage).
+template <int NFT, int R, bool LDW, bool LDA, bool LDB, bool FIRST_B = false>
+__device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][NFT], f32x4 (&bA)[6], f32x4 (&bB)[6],
+                                           const f32x16 (&bv)[NFT], const WSrc& wl, int wstride, const char* bl, int s) {
+    constexpr int RL = (R + 3) % 6;
+    if (LDW) {
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) w[RL][ft] = wload(wl, s + 3, wstride, ft);
+    }
+    if (LDA) bA[RL] = *(const f32x4*)(bl + (s + 3) * 2048);
+    if (LDB) bB[RL] = *(const f32x4*)(bl + 1024 + (s + 1) * 2048);
+    skew_mfmas<NFT, R, true, true, false, FIRST_B>(acc, w, bA, bB, bv);
+    constexpr int NM = 8 * NFT;
+    constexpr int NV = LDW ? NFT : 0, ND = (LDA ? 1 : 0) + (LDB ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - ND, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// A one-tile stage (4*NFT MFMAs) with one piece of the other tile's epilogue behind every MFMA.
+//   TILE: the tile whose MFMAs run (0 = A at the head of a layer, 1 = B at its tail); the epilogue is the other's.
+//   STORE false: piece = leaky-ReLU of one register quad; true: piece = its ds_write_b128.
+template <int NFT, int R, int TILE, bool STORE, bool FIRST>
+__device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32x4 (&w)[6][NFT],
+                                                const f32x4 (&bA)[6], const f32x4 (&bB)[6],
+                                                const f32x16 (&bv)[NFT], float alpha, char* st_base) {
+    constexpr int WS = (TILE == 0) ? R : (R + 4) % 6;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const float b = (TILE == 0) ? bA[R][e] : bB[R][e];
+            acc[ft][TILE] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[WS][ft][e], b,
+                                                                 (FIRST && e == 0) ? bv[ft] : acc[ft][TILE], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int idx = e * NFT + ft;
+            if (STORE) store_quad<NFT>(acc, 1 - TILE, idx, st_base);
+            else lrelu_quad(acc[idx >> 2][1 - TILE], idx & 3, alpha);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// One hidden layer with K = 8*NKG.  On entry: w[0..2] hold (requests for) this layer's k-groups 0..2, bv its bias;
+// tile A's input image is published; acc[.][1] holds the PREVIOUS layer's tile-B pre-activations, not yet stored, and
+// every wave is done reading tile B's image.  On return the same holds one layer on (wn / bias_n = the next layer's
+// weights and bias; when there is none the caller passes this layer's again and ignores the result).
+template <int NFT, int NKG>
+__device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][NFT], f32x16 (&bv)[NFT],
+                                           const WSrc& wl, const WSrc& wn, const float* bias_n, int wstride,
+                                           const char* bl, char* st_base, float alpha, int wave, int lane) {
+    static_assert((NKG + 2) % 6 == 0 && NKG >= 16, "ring of 6 needs NKG + 2 to be a multiple of 6");
+    f32x4 bA[6], bB[6];
+    bA[0] = *(const f32x4*)(bl);
+    bA[1] = *(const f32x4*)(bl + 2048);
+    bA[2] = *(const f32x4*)(bl + 4096);
+    // ---- stage 0: A only; previous layer's tile B activated in the shadow --------------------------------
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) w[3][ft] = wload(wl, 3, wstride, ft);
+    bA[3] = *(const f32x4*)(bl + 3 * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    skew_edge_stage<NFT, 0, 0, false, true>(acc, w, bA, bB, bv, alpha, st_base);
+    // ---- stage 1: A only; previous layer's tile B stored in the shadow -----------------------------------
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) w[4][ft] = wload(wl, 4, wstride, ft);
+    bA[4] = *(const f32x4*)(bl + 4 * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    skew_edge_stage<NFT, 1, 0, true, false>(acc, w, bA, bB, bv, alpha, st_base);
+    __syncthreads();   // tile B's image is published
+    bB[2] = *(const f32x4*)(bl + 1024);
+    bB[3] = *(const f32x4*)(bl + 1024 + 2048);
+    bB[4] = *(const f32x4*)(bl + 1024 + 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stages 2..5 ------------------------------------------------------------------------------------------
+    skew_stage<NFT, 2, true, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 2);
+    skew_stage<NFT, 3, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 3);
+    skew_stage<NFT, 4, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 4);
+    skew_stage<NFT, 5, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 5);
+    // ---- stages 6 .. NKG-5 -----------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int s = 6; s < NKG - 4; s += 6) {
+        skew_stage<NFT, 0, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s);
+        skew_stage<NFT, 1, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 1);
+        skew_stage<NFT, 2, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 2);
+        skew_stage<NFT, 3, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 3);
+        skew_stage<NFT, 4, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 4);
+        skew_stage<NFT, 5, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 5);
+    }
+    // ---- stages NKG-4 .. NKG-1: the last requests of this layer ---------------------------------------------
+    skew_stage<NFT, 0, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 4);
+    skew_stage<NFT, 1, false, false, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 3);
+    skew_stage<NFT, 2, false, false, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 2);
+    // stage NKG-1 also requests the next layer's bias and its k-group 0 (ring slot 0 is free: B used it at NKG-2)
+    load_bias<NFT>(bv, bias_n, wave, lane);
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) w[0][ft] = wload(wn, 0, wstride, ft);
+    __builtin_amdgcn_sched_barrier(0);
+    skew_stage<NFT, 3, false, false, false>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 1);
+    // ---- stage NKG: B only; tile A activated in the shadow ---------------------------------------------------
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) w[1][ft] = wload(wn, 1, wstride, ft);
+    __builtin_amdgcn_sched_barrier(0);
+    skew_edge_stage<NFT, 4, 1, false, false>(acc, w, bA, bB, bv, alpha, st_base);
+    __syncthreads();   // every wave is done reading tile A's image
+    // ---- stage NKG+1: B only; tile A stored in the shadow ----------------------------------------------------
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) w[2][ft] = wload(wn, 2, wstride, ft);
+    __builtin_amdgcn_sched_barrier(0);
+    skew_edge_stage<NFT, 5, 1, true, false>(acc, w, bA, bB, bv, alpha, st_base);
+    __syncthreads();   // tile A's image is published; every wave is done reading tile B's
+}
+
+// All hidden layers after layer 0.  On entry acc holds layer 0's pre-activations of both tiles (bias included); on
+// return the last hidden layer's activations are in the image, the closing barrier still to come (the caller
+// requests the output layer's weights first).
+template <int HID>
+__device__ __forceinline__ void hidden_skewed(const MlpArgs& m, f32x16 (&acc)[HID / 128][2], f32x16 (&bv)[HID / 128],
+                                              char* act, int wave, int lane) {
+    constexpr int NFT = HID / 128, FTT = HID / 32, NKG = HID / 8;
+    const int h = lane >> 5, j = lane & 31;
+    const int nhid = m.n_layers - 1;
+    char* st_base = act + act_off<64>(4 * wave * NFT, j, h);
+    const char* bl = act + act_off<64>(0, j, h);
+    f32x4 w[6][NFT];
+    WSrc wl = make_wsrc(m.wp[nhid > 1 ? 1 : 0] + (wave * NFT) * 256, lane);
+    if (nhid > 1) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) w[g][ft] = wload(wl, g, FTT * 64, ft);
+        load_bias<NFT>(bv, m.bp[1], wave, lane);
+    }
+    // layer 0's tile A (nothing to hide behind yet)
+#pragma unroll
+    for (int idx = 0; idx < 4 * NFT; ++idx) {
+        lrelu_quad(acc[idx >> 2][0], idx & 3, m.alpha);
+        store_quad<NFT>(acc, 0, idx, st_base);
+    }
+    __syncthreads();
+    for (int l = 1; l < nhid; ++l) {
+        const int ln = (l + 1 < nhid) ? l + 1 : l;
+        const WSrc wn = make_wsrc(m.wp[ln] + (wave * NFT) * 256, lane);
+        skew_layer<NFT, NKG>(acc, w, bv, wl, wn, m.bp[ln], FTT * 64, bl, st_base, m.alpha, wave, lane);
+        wl = wn;
+    }
+    // the last hidden layer's tile B
+#pragma unroll
+    for (int idx = 0; idx < 4 * NFT; ++idx) {
+        lrelu_quad(acc[idx >> 2][1], idx & 3, m.alpha);
+        store_quad<NFT>(acc, 1, idx, st_base);
+    }
+}
+
 // Output layer for NT feature tiles, K split over the four waves; partial sums go to
 // part[(wave*out_dim + d)*MS + s] (floats, aliases the activation image).
 template <int NT, int NST>
@@ -427,42 +631,52 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     load_bias<NFT>(bv, m.bp[0], wave, lane);
     gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
                                     x0 + act_off<MS>(0, j, h), bv);
-    // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
-    constexpr bool ACT0 = (NST == 2) && !JVP;
-    if constexpr (ACT0) {
-#pragma unroll
-        for (int ft = 0; ft < NFT; ++ft)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lrelu_quad(acc[ft][0], q, m.alpha);
-    }
-    ST(1)
     const int nhid = m.n_layers - 1;
-    f32x4 a0[NFT], a1[NFT], a2[NFT];
     constexpr int KQ = HID / 32;        // k-groups per wave in the output layer
     const bool small_out = (NST == 2) && m.wsmall != nullptr;
-    for (int l = 0; l + 1 < nhid; ++l) {
-        const WSrc wnext = make_wsrc(m.wp[l + 1] + (wave * NFT) * 256, lane);
-        prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
-        if (l > 0) __syncthreads();   // all waves finished reading layer l's input
+    f32x4 wsm[2 * KQ];
+    constexpr bool SKEWED = (NST == 2) && !JVP && ((HID / 8 + 2) % 6 == 0);
+    if constexpr (SKEWED) {
+        ST(1)
+        hidden_skewed<HID>(m, acc, bv, act, wave, lane);
+        ST(5)
+        if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
+        __syncthreads();
+        ST(4)
+    } else {
+        // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
+        constexpr bool ACT0 = (NST == 2) && !JVP;
+        if constexpr (ACT0) {
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lrelu_quad(acc[ft][0], q, m.alpha);
+        }
+        ST(1)
+        f32x4 a0[NFT], a1[NFT], a2[NFT];
+        for (int l = 0; l + 1 < nhid; ++l) {
+            const WSrc wnext = make_wsrc(m.wp[l + 1] + (wave * NFT) * 256, lane);
+            prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
+            if (l > 0) __syncthreads();   // all waves finished reading layer l's input
+            ST(2)
+            store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
+            load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
+            ST(3)
+            __syncthreads();
+            ST(4)
+            gemm_tile<NFT, NST, JVP, ACT0>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv, m.alpha);
+            ST(5)
+        }
+        // the last hidden layer's epilogue (kept out of the loop so the output layer's prefetched weights are not
+        // live across the hidden layers' K loops)
+        if (nhid > 1) __syncthreads();
         ST(2)
         store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
-        load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
+        if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
         ST(3)
         __syncthreads();
         ST(4)
-        gemm_tile<NFT, NST, JVP, ACT0>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv, m.alpha);
-        ST(5)
     }
-    // the last hidden layer's epilogue (kept out of the loop so the output layer's prefetched weights are not live
-    // across the hidden layers' K loops)
-    f32x4 wsm[2 * KQ];
-    if (nhid > 1) __syncthreads();
-    ST(2)
-    store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
-    if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
-    ST(3)
-    __syncthreads();
-    ST(4)
     float* part = (float*)act;
     if (small_out) {
         last_layer_small<KQ>(m, wsm, act, part, wave, lane);
