@@ -377,34 +377,38 @@ __device__ __forceinline__ void store_quad(const f32x16 (&t)[NFT][2], int st, in
 
 // The MFMAs of ring position R.  DO_A / DO_B: which tiles take part; FIRST_*: the tile's first k-group (C = bias).
 template <int NFT, int R, bool DO_A, bool DO_B, bool FIRST_A, bool FIRST_B>
-__device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&w)[6][NFT], const f32x4 (&bA)[6],
-                                           const f32x4 (&bB)[6], const f32x16 (&bv)[NFT]) {
+__device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&wA)[NFT], const f32x4 (&wB)[NFT],
+                                           const f32x4 (&bA)[6], const f32x4 (&bB)[6], const f32x16 (&bv)[NFT]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
             if (DO_A)
-                acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[R][ft][e], bA[R][e],
+                acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[ft][e], bA[R][e],
                                                                   (FIRST_A && e == 0) ? bv[ft] : acc[ft][0], 0, 0, 0);
             if (DO_B)
-                acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(R + 4) % 6][ft][e], bB[R][e],
+                acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[ft][e], bB[R][e],
                                                                   (FIRST_B && e == 0) ? bv[ft] : acc[ft][1], 0, 0, 0);
         }
 }
 
 // A steady stage s (ring position R = s % 6): requests the operands of three stages ahead, runs both tiles' MFMAs,
 // and pins one memory instruction behind each of the first MFMAs (see pipe_stage).
+//   wA / wB: the weights A and B use in this stage (ring slots, or the layer's first three k-groups in wh)
+//   wld:     where the LDW request goes (ring slot (R+3)%6, or the NEXT layer's wh) and from which source / k-group
 template <int NFT, int R, bool LDW, bool LDA, bool LDB, bool FIRST_B = false>
-__device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][NFT], f32x4 (&bA)[6], f32x4 (&bB)[6],
-                                           const f32x16 (&bv)[NFT], const WSrc& wl, int wstride, const char* bl, int s) {
+__device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wA)[NFT], const f32x4 (&wB)[NFT],
+                                           f32x4 (&wld)[NFT], f32x4 (&bA)[6], f32x4 (&bB)[6],
+                                           const f32x16 (&bv)[NFT], const WSrc& wl, int wstride, int kgw,
+                                           const char* bl, int s) {
     constexpr int RL = (R + 3) % 6;
     if (LDW) {
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) w[RL][ft] = wload(wl, s + 3, wstride, ft);
+        for (int ft = 0; ft < NFT; ++ft) wld[ft] = wload(wl, kgw, wstride, ft);
     }
     if (LDA) bA[RL] = *(const f32x4*)(bl + (s + 3) * 2048);
     if (LDB) bB[RL] = *(const f32x4*)(bl + 1024 + (s + 1) * 2048);
-    skew_mfmas<NFT, R, true, true, false, FIRST_B>(acc, w, bA, bB, bv);
+    skew_mfmas<NFT, R, true, true, false, FIRST_B>(acc, wA, wB, bA, bB, bv);
     constexpr int NM = 8 * NFT;
     constexpr int NV = LDW ? NFT : 0, ND = (LDA ? 1 : 0) + (LDB ? 1 : 0);
 #pragma unroll
@@ -425,16 +429,15 @@ __device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][
 //   TILE: the tile whose MFMAs run (0 = A at the head of a layer, 1 = B at its tail); the epilogue is the other's.
 //   STORE false: piece = leaky-ReLU of one register quad; true: piece = its ds_write_b128.
 template <int NFT, int R, int TILE, bool STORE, bool FIRST>
-__device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32x4 (&w)[6][NFT],
+__device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wt)[NFT],
                                                 const f32x4 (&bA)[6], const f32x4 (&bB)[6],
                                                 const f32x16 (&bv)[NFT], float alpha, char* st_base) {
-    constexpr int WS = (TILE == 0) ? R : (R + 4) % 6;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
             const float b = (TILE == 0) ? bA[R][e] : bB[R][e];
-            acc[ft][TILE] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[WS][ft][e], b,
+            acc[ft][TILE] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ft][e], b,
                                                                  (FIRST && e == 0) ? bv[ft] : acc[ft][TILE], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int idx = e * NFT + ft;
@@ -444,16 +447,18 @@ __device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32
         }
 }
 
-// One hidden layer with K = 8*NKG.  On entry: w[0..2] hold (requests for) this layer's k-groups 0..2, bv its bias;
-// tile A's input image is published; acc[.][1] holds the PREVIOUS layer's tile-B pre-activations, not yet stored, and
-// every wave is done reading tile B's image.  On return the same holds one layer on (wn / bias_n = the next layer's
-// weights and bias; when there is none the caller passes this layer's again and ignores the result).
+// One hidden layer with K = 8*NKG.  The weights of its k-groups 0..2 live in wh (outside the ring), so that the NEXT
+// layer's can be requested as early as stage NKG-3 — two thousand cycles before they are used.  On entry: wh holds
+// (requests for) this layer's k-groups 0..2, bv its bias; tile A's input image is published; acc[.][1] holds the PREVIOUS
+// layer's tile-B pre-activations, not yet stored, and every wave is done reading tile B's image.  On return the same
+// holds one layer on (wn / bias_n = the next layer's weights and bias; when there is none the caller passes this
+// layer's again and ignores the result).
 template <int NFT, int NKG>
-__device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][NFT], f32x16 (&bv)[NFT],
+__device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x16 (&bv)[NFT],
                                            const WSrc& wl, const WSrc& wn, const float* bias_n, int wstride,
-                                           const char* bl, char* st_base, float alpha, int wave, int lane) {
+                                           const char* bl, char* st_base, float alpha, int wave, int lane ST_PARAM) {
     static_assert((NKG + 2) % 6 == 0 && NKG >= 16, "ring of 6 needs NKG + 2 to be a multiple of 6");
-    f32x4 bA[6], bB[6];
+    f32x4 w[6][NFT], bA[6], bB[6];
     bA[0] = *(const f32x4*)(bl);
     bA[1] = *(const f32x4*)(bl + 2048);
     bA[2] = *(const f32x4*)(bl + 4096);
@@ -462,55 +467,51 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][
     for (int ft = 0; ft < NFT; ++ft) w[3][ft] = wload(wl, 3, wstride, ft);
     bA[3] = *(const f32x4*)(bl + 3 * 2048);
     __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 0, 0, false, true>(acc, w, bA, bB, bv, alpha, st_base);
+    skew_edge_stage<NFT, 0, 0, false, true>(acc, wh[0], bA, bB, bv, alpha, st_base);
     // ---- stage 1: A only; previous layer's tile B stored in the shadow -----------------------------------
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) w[4][ft] = wload(wl, 4, wstride, ft);
     bA[4] = *(const f32x4*)(bl + 4 * 2048);
     __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 1, 0, true, false>(acc, w, bA, bB, bv, alpha, st_base);
+    skew_edge_stage<NFT, 1, 0, true, false>(acc, wh[1], bA, bB, bv, alpha, st_base);
+    ST(2)
     __syncthreads();   // tile B's image is published
+    ST(3)
     bB[2] = *(const f32x4*)(bl + 1024);
     bB[3] = *(const f32x4*)(bl + 1024 + 2048);
     bB[4] = *(const f32x4*)(bl + 1024 + 4096);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- stages 2..5 ------------------------------------------------------------------------------------------
-    skew_stage<NFT, 2, true, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 2);
-    skew_stage<NFT, 3, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 3);
-    skew_stage<NFT, 4, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 4);
-    skew_stage<NFT, 5, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, 5);
+    // ---- stages 2..5: A on wh[2], w[3..5]; B on wh[0..2], w[3] ------------------------------------------------
+    skew_stage<NFT, 2, true, true, true, true>(acc, wh[2], wh[0], w[5], bA, bB, bv, wl, wstride, 5, bl, 2);
+    skew_stage<NFT, 3, true, true, true>(acc, w[3], wh[1], w[0], bA, bB, bv, wl, wstride, 6, bl, 3);
+    skew_stage<NFT, 4, true, true, true>(acc, w[4], wh[2], w[1], bA, bB, bv, wl, wstride, 7, bl, 4);
+    skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, bv, wl, wstride, 8, bl, 5);
     // ---- stages 6 .. NKG-5 -----------------------------------------------------------------------------------
 #pragma unroll 1
     for (int s = 6; s < NKG - 4; s += 6) {
-        skew_stage<NFT, 0, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s);
-        skew_stage<NFT, 1, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 1);
-        skew_stage<NFT, 2, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 2);
-        skew_stage<NFT, 3, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 3);
-        skew_stage<NFT, 4, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 4);
-        skew_stage<NFT, 5, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, s + 5);
+        skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, bv, wl, wstride, s + 3, bl, s);
+        skew_stage<NFT, 1, true, true, true>(acc, w[1], w[5], w[4], bA, bB, bv, wl, wstride, s + 4, bl, s + 1);
+        skew_stage<NFT, 2, true, true, true>(acc, w[2], w[0], w[5], bA, bB, bv, wl, wstride, s + 5, bl, s + 2);
+        skew_stage<NFT, 3, true, true, true>(acc, w[3], w[1], w[0], bA, bB, bv, wl, wstride, s + 6, bl, s + 3);
+        skew_stage<NFT, 4, true, true, true>(acc, w[4], w[2], w[1], bA, bB, bv, wl, wstride, s + 7, bl, s + 4);
+        skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, bv, wl, wstride, s + 8, bl, s + 5);
     }
-    // ---- stages NKG-4 .. NKG-1: the last requests of this layer ---------------------------------------------
-    skew_stage<NFT, 0, true, true, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 4);
-    skew_stage<NFT, 1, false, false, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 3);
-    skew_stage<NFT, 2, false, false, true>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 2);
-    // stage NKG-1 also requests the next layer's bias and its k-group 0 (ring slot 0 is free: B used it at NKG-2)
+    // ---- stages NKG-4 .. NKG-1: this layer's last requests, then the next layer's first k-groups and bias -------
+    skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, bv, wl, wstride, NKG - 1, bl, NKG - 4);
+    skew_stage<NFT, 1, true, false, true>(acc, w[1], w[5], wh[0], bA, bB, bv, wn, wstride, 0, bl, NKG - 3);
+    skew_stage<NFT, 2, true, false, true>(acc, w[2], w[0], wh[1], bA, bB, bv, wn, wstride, 1, bl, NKG - 2);
     load_bias<NFT>(bv, bias_n, wave, lane);
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) w[0][ft] = wload(wn, 0, wstride, ft);
-    __builtin_amdgcn_sched_barrier(0);
-    skew_stage<NFT, 3, false, false, false>(acc, w, bA, bB, bv, wl, wstride, bl, NKG - 1);
+    skew_stage<NFT, 3, true, false, false>(acc, w[3], w[1], wh[2], bA, bB, bv, wn, wstride, 2, bl, NKG - 1);
     // ---- stage NKG: B only; tile A activated in the shadow ---------------------------------------------------
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) w[1][ft] = wload(wn, 1, wstride, ft);
-    __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 4, 1, false, false>(acc, w, bA, bB, bv, alpha, st_base);
+    skew_edge_stage<NFT, 4, 1, false, false>(acc, w[2], bA, bB, bv, alpha, st_base);
+    ST(5)
     __syncthreads();   // every wave is done reading tile A's image
+    ST(4)
     // ---- stage NKG+1: B only; tile A stored in the shadow ----------------------------------------------------
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) w[2][ft] = wload(wn, 2, wstride, ft);
-    __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 5, 1, true, false>(acc, w, bA, bB, bv, alpha, st_base);
+    skew_edge_stage<NFT, 5, 1, true, false>(acc, w[3], bA, bB, bv, alpha, st_base);
+    ST(5)
     __syncthreads();   // tile A's image is published; every wave is done reading tile B's
+    ST(4)
 }
 
 // All hidden layers after layer 0.  On entry acc holds layer 0's pre-activations of both tiles (bias included); on
@@ -518,19 +519,19 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&w)[6][
 // requests the output layer's weights first).
 template <int HID>
 __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, f32x16 (&acc)[HID / 128][2], f32x16 (&bv)[HID / 128],
-                                              char* act, int wave, int lane) {
+                                              char* act, int wave, int lane ST_PARAM) {
     constexpr int NFT = HID / 128, FTT = HID / 32, NKG = HID / 8;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
     char* st_base = act + act_off<64>(4 * wave * NFT, j, h);
     const char* bl = act + act_off<64>(0, j, h);
-    f32x4 w[6][NFT];
+    f32x4 wh[3][NFT];
     WSrc wl = make_wsrc(m.wp[nhid > 1 ? 1 : 0] + (wave * NFT) * 256, lane);
     if (nhid > 1) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) w[g][ft] = wload(wl, g, FTT * 64, ft);
+            for (int ft = 0; ft < NFT; ++ft) wh[g][ft] = wload(wl, g, FTT * 64, ft);
         load_bias<NFT>(bv, m.bp[1], wave, lane);
     }
     // layer 0's tile A (nothing to hide behind yet)
@@ -543,7 +544,7 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, f32x16 (&acc)[HI
     for (int l = 1; l < nhid; ++l) {
         const int ln = (l + 1 < nhid) ? l + 1 : l;
         const WSrc wn = make_wsrc(m.wp[ln] + (wave * NFT) * 256, lane);
-        skew_layer<NFT, NKG>(acc, w, bv, wl, wn, m.bp[ln], FTT * 64, bl, st_base, m.alpha, wave, lane);
+        skew_layer<NFT, NKG>(acc, wh, bv, wl, wn, m.bp[ln], FTT * 64, bl, st_base, m.alpha, wave, lane ST_ARG);
         wl = wn;
     }
     // the last hidden layer's tile B
@@ -638,11 +639,11 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, 
     constexpr bool SKEWED = (NST == 2) && !JVP && ((HID / 8 + 2) % 6 == 0);
     if constexpr (SKEWED) {
         ST(1)
-        hidden_skewed<HID>(m, acc, bv, act, wave, lane);
-        ST(5)
+        hidden_skewed<HID>(m, acc, bv, act, wave, lane ST_ARG);
+        ST(1)
         if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
         __syncthreads();
-        ST(4)
+        ST(1)
     } else {
         // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
         constexpr bool ACT0 = (NST == 2) && !JVP;

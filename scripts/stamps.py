@@ -21,7 +21,12 @@ eng.reset_counters()
 eng.is_estimate(y, xh, 6400, 0.1, 0.5)
 c = eng.counters()
 lib.rt_debug_stamps(eng._h, buf, 1)
-names = ["sample+barrier", "layer0 gemm", "wait-all-read barrier", "store_act", "post-store barrier", "hidden gemm", "last layer", "score+lse"]
+# plain schedule (widths 256/1024): 2 = wait-all-read barrier, 3 = store_act, 4 = post-store barrier, 5 = hidden gemm
+# skewed schedule (widths 128/512):  1 also holds the first / last half-epilogues, 2 = head stages 0-1 (A MFMAs +
+# B's epilogue), 3 = barrier before stage 2, 4 = the two barriers around stage NKG+1, 5 = stages 2 .. NKG+1
+names = ["sample+barrier", "layer0 + unhidden half-epilogues", "head stages (skewed) / wait-all-read barrier",
+         "barrier after head (skewed) / store_act", "tail barriers (skewed) / post-store barrier",
+         "hidden MFMA stages", "last layer", "score+lse"]
 a = np.array(list(buf), dtype=np.float64).reshape(4, 8)
 print("kernel ms", c["kernel_ms"], "TF", c["flops"] / c["kernel_ms"] / 1e9)
 for w in range(4):
