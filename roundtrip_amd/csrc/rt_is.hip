@@ -483,6 +483,11 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     __builtin_amdgcn_sched_barrier(0);
     // ---- stages 2..5: A on wh[2], w[3..5]; B on wh[0..2], w[3] ------------------------------------------------
     skew_stage<NFT, 2, true, true, true, true>(acc, wh[2], wh[0], w[5], bA, bB, bv, wl, wstride, 5, bl, 2);
+    // Keep the bias registers alive past tile B's first MFMA: were it their last use, hipcc would accumulate B in place
+    // in them, the roles of "bias" and "tile B's accumulators" would swap every layer, and the layer loop would pay for
+    // it with 64 register moves in the middle of the last stage's MFMA chain plus 52 on the back edge.
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) asm volatile("" ::"v"(bv[ft]));
     skew_stage<NFT, 3, true, true, true>(acc, w[3], wh[1], w[0], bA, bB, bv, wl, wstride, 6, bl, 3);
     skew_stage<NFT, 4, true, true, true>(acc, w[4], wh[2], w[1], bA, bB, bv, wl, wstride, 7, bl, 4);
     skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, bv, wl, wstride, 8, bl, 5);
