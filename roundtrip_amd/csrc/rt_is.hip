@@ -55,11 +55,16 @@ struct MlpArgs {
 // Diagnostic build only (-DRT_STAMPS, scripts/stamps.py): per-phase s_memtime sums of workgroup 0's waves.
 // In the shipped library none of this exists.
 #ifdef RT_STAMPS
-__device__ unsigned long long g_stamps[4 * 8];
-struct Stamps { unsigned long long t, acc[8]; };
+constexpr int NSTAMP = 14;
+__device__ unsigned long long g_stamps[4 * NSTAMP];
+struct Stamps { unsigned long long t, acc[NSTAMP]; };
 #define ST_PARAM , Stamps& st
 #define ST_ARG , st
+#if RT_STAMPS == 2   // -DRT_STAMPS=2: only the fused kernel's total (slot 0), nothing inside it is perturbed
+#define ST(i)
+#else
 #define ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st.acc[i] += n_ - st.t; st.t = n_; }
+#endif
 #else
 #define ST_PARAM
 #define ST_ARG
@@ -138,7 +143,9 @@ __device__ __forceinline__ WSrc make_wsrc(const float* base, int lane) {
 // A operands of (k-group kg, feature tile ft); wstride = f32x4 elements between k-groups.
 __device__ __forceinline__ f32x4 wload(const WSrc& w, int kg, int wstride, int ft) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, w.voff + ft * 1024, kg * wstride * 16, 0);
+    // ft * 1024 goes through the SCALAR offset: as part of the vector offset hipcc hoists the four sums out of the
+    // layer loop into registers of their own (AGPRs, read back with a VALU instruction before every load)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, w.voff, kg * wstride * 16 + ft * 1024, 0);
     return __builtin_bit_cast(f32x4, v);
 }
 
@@ -351,23 +358,54 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
 }
 
 // ----------------------------------------------------------------------------------------------
-// Skewed hidden layers (64-sample passes; not the Jacobian kernel): the epilogue hides behind MFMAs.
+// Skewed hidden layers (64-sample passes; not the Jacobian kernel).
 //
-// A layer's epilogue stores 128 KB of activations per CU through ds_write_b128 (~79 B/clk/CU): ~2700 cycles
-// during which, in the plain schedule (gemm_tile + store_act), no MFMA issues, because the image is updated in
-// place and cannot be double-buffered in 160 KB.  Here sample tile 1 ("B") runs SKEW = 2 k-groups behind sample
-// tile 0 ("A") inside the same K loop: a stage s issues A's MFMAs for k-group s and B's for k-group s-2, with the
-// weights of a k-group kept in registers two stages longer (ring of 6).  A layer is NKG + 2 stages:
-//   stages 0, 1        A only; the PREVIOUS layer's tile B is activated (stage 0) and stored (stage 1) in the
-//                      MFMAs' shadow; barrier (B's image is published) before stage 2
-//   stages 2 .. NKG-1  A and B
-//   stages NKG, NKG+1  B only; THIS layer's tile A is activated (stage NKG) and stored (stage NKG+1) in the
-//                      MFMAs' shadow; a barrier before the stores (every wave is done reading A's image),
-//                      one after them (A's image is published, every wave is done reading B's image)
+// What the hardware allows (scripts/ubench_coexec.hip, measured on MI355X): a SIMD's fp32 MFMA and its VALU never run
+// at the same time.  A VALU instruction between two MFMAs costs its full 4-5 cycles plus ~11 cycles for the
+// MFMA -> VALU -> MFMA switch, whether it comes from the same wave or from a second wave on the SIMD; ds_read /
+// ds_write (up to one ds_write_b128 per MFMA and wave, the LDS rate), buffer loads, scalar instructions and barriers
+// between MFMAs are free.  So a layer's epilogue splits into arithmetic that must be paid for — the leaky-ReLU, as ONE
+// uninterrupted VALU cluster per sample tile — and traffic that can hide behind MFMAs: the ds_write_b128 stores of the
+// activation image, the next operand reads and the barriers (the image is updated in place; it cannot be
+// double-buffered in 160 KB).
+//
+// Sample tile 1 ("B") runs SKEW = 2 k-groups behind sample tile 0 ("A") inside the same K loop: a stage s issues A's
+// MFMAs for k-group s and B's for k-group s-2, with the weights of a k-group kept in registers two stages longer
+// (ring of 6).  A layer is NKG + 2 stages:
+//   stage 0          A only (C = bias); the PREVIOUS layer's tile B, already activated, is stored, one ds_write_b128
+//                    behind each MFMA;  barrier P: B's image is published
+//   stage 1          A only; B's operands of k-groups 0..2 are requested
+//   stages 2..NKG-1  A and B
+//                    barrier Q: every wave has read all of A's image;  A's leaky-ReLU cluster
+//   stage NKG        B only; tile A is stored behind the MFMAs;  barrier R: A's image is published
+//   stage NKG+1      B only; the NEXT layer's A operands of k-groups 0..2 are requested
+//                    barrier S: every wave has read all of B's image;  B's leaky-ReLU cluster
+// Every barrier has MFMAs in flight or a VALU cluster next to it, and no operand read waits on one.
 // Every accumulator sees its k's in the same order as in the plain schedule, so results are bit-identical.
 // Ring slots: weights of k-group g in w[g % 6]; A's operand of k-group g in bA[g % 6]; B's in bB[(g + 2) % 6];
 // all three are requested three stages before their first use.  Needs (NKG + 2) % 6 == 0: widths 128 and 512.
 // ----------------------------------------------------------------------------------------------
+// LDS operand reads of the skewed schedule: byte offset `off` from this lane's base bl.  ds_read_b128 carries a 16-bit
+// immediate offset; with a second base at +64 KB every (compile-time) offset is an immediate and the fully unrolled
+// K loop has no address arithmetic on the VALU, where a lone instruction between MFMAs costs ~15 cycles.
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+struct LdsBase {
+    lds_cptr lo;   // bl
+    lds_cptr hi;   // bl + 65536
+};
+__device__ __forceinline__ LdsBase make_lds_base(const char* p) {
+    LdsBase b;
+    b.lo = (lds_cptr)p;
+    unsigned hi = (unsigned)(size_t)b.lo + 65536u;
+    asm volatile("" : "+v"(hi));   // opaque: or hipcc folds hi back into lo + 64 KB and adds once per read
+    b.hi = (lds_cptr)(size_t)hi;
+    return b;
+}
+__device__ __forceinline__ f32x4 lds_operand(const LdsBase& b, int off) {
+    typedef const __attribute__((address_space(3))) f32x4* vp;
+    return (off < 65536) ? *(vp)(b.lo + off) : *(vp)(b.hi + (off - 65536));
+}
+
 template <int NFT>
 __device__ __forceinline__ void store_quad(const f32x16 (&t)[NFT][2], int st, int idx, char* st_base) {
     const int ft = idx >> 2, q = idx & 3;
@@ -375,20 +413,55 @@ __device__ __forceinline__ void store_quad(const f32x16 (&t)[NFT][2], int st, in
     *(f32x4*)(st_base + (4 * ft + q) * 2048 + st * 1024) = v;
 }
 
-// The MFMAs of ring position R.  DO_A / DO_B: which tiles take part; FIRST_*: the tile's first k-group (C = bias).
-template <int NFT, int R, bool DO_A, bool DO_B, bool FIRST_A, bool FIRST_B>
+// leaky-ReLU of a whole sample tile in place, as one VALU cluster
+template <int NFT, int TILE>
+__device__ __forceinline__ void lrelu_tile(f32x16 (&acc)[NFT][2], float alpha) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lrelu_quad(acc[ft][TILE], q, alpha);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Bias of one register quad (idx = 4*ft + q) of tile TILE, loaded straight INTO the accumulators: a layer's first MFMA
+// then accumulates onto it like any other (no separate bias registers, no special first k-step).  bias: the layer's
+// padded bias vector as a buffer resource; voff: this lane's byte offset (32*wave*NFT + 4h)*4.
+// A bias load overwrites registers a ds_write_b128 has just read: it follows that store BLAG MFMAs later, when the store
+// has long left the LDS queue (directly behind it, hipcc's WAR wait for the store stalls the wave for the LDS latency).
+#ifndef RT_BLAG
+#define RT_BLAG 3
+#endif
+template <int NFT>
+constexpr int blag() { return RT_BLAG < 4 * NFT ? RT_BLAG : 4 * NFT; }
+struct BiasSrc {
+    __amdgpu_buffer_rsrc_t r;
+    int voff;
+};
+__device__ __forceinline__ BiasSrc make_bias(const float* bias, int voff) {
+    BiasSrc b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, 0x7fffffff, 0x00020000);
+    b.voff = voff;
+    return b;
+}
+template <int NFT, int TILE>
+__device__ __forceinline__ void bias_quad(f32x16 (&acc)[NFT][2], const BiasSrc& bs, int idx) {
+    const int ft = idx >> 2, q = idx & 3;
+    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bs.r, bs.voff, (32 * ft + 8 * q) * 4, 0));
+    acc[ft][TILE][4 * q] = t[0]; acc[ft][TILE][4 * q + 1] = t[1];
+    acc[ft][TILE][4 * q + 2] = t[2]; acc[ft][TILE][4 * q + 3] = t[3];
+}
+
+// The MFMAs of ring position R for both tiles.
+template <int NFT, int R>
 __device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&wA)[NFT], const f32x4 (&wB)[NFT],
-                                           const f32x4 (&bA)[6], const f32x4 (&bB)[6], const f32x16 (&bv)[NFT]) {
+                                           const f32x4 (&bA)[6], const f32x4 (&bB)[6]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
-            if (DO_A)
-                acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[ft][e], bA[R][e],
-                                                                  (FIRST_A && e == 0) ? bv[ft] : acc[ft][0], 0, 0, 0);
-            if (DO_B)
-                acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[ft][e], bB[R][e],
-                                                                  (FIRST_B && e == 0) ? bv[ft] : acc[ft][1], 0, 0, 0);
+            acc[ft][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[ft][e], bA[R][e], acc[ft][0], 0, 0, 0);
+            acc[ft][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[ft][e], bB[R][e], acc[ft][1], 0, 0, 0);
         }
 }
 
@@ -396,21 +469,25 @@ __device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&
 // and pins one memory instruction behind each of the first MFMAs (see pipe_stage).
 //   wA / wB: the weights A and B use in this stage (ring slots, or the layer's first three k-groups in wh)
 //   wld:     where the LDW request goes (ring slot (R+3)%6, or the NEXT layer's wh) and from which source / k-group
-template <int NFT, int R, bool LDW, bool LDA, bool LDB, bool FIRST_B = false>
+template <int NFT, int R, bool LDW, bool LDA, bool LDB>
 __device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wA)[NFT], const f32x4 (&wB)[NFT],
                                            f32x4 (&wld)[NFT], f32x4 (&bA)[6], f32x4 (&bB)[6],
-                                           const f32x16 (&bv)[NFT], const WSrc& wl, int wstride, int kgw,
-                                           const char* bl, int s) {
+                                           const WSrc& wl, int wstride, int kgw, const LdsBase& bl, int s) {
     constexpr int RL = (R + 3) % 6;
-    if (LDW) {
+#ifdef RT_ABL   // timing ablation (diagnostic builds only; results are garbage): 1 = no weight loads, 2 = no LDS reads
+    constexpr bool LDW_ = LDW && !(RT_ABL & 1), LDA_ = LDA && !(RT_ABL & 2), LDB_ = LDB && !(RT_ABL & 2);
+#else
+    constexpr bool LDW_ = LDW, LDA_ = LDA, LDB_ = LDB;
+#endif
+    if (LDW_) {
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) wld[ft] = wload(wl, kgw, wstride, ft);
     }
-    if (LDA) bA[RL] = *(const f32x4*)(bl + (s + 3) * 2048);
-    if (LDB) bB[RL] = *(const f32x4*)(bl + 1024 + (s + 1) * 2048);
-    skew_mfmas<NFT, R, true, true, false, FIRST_B>(acc, wA, wB, bA, bB, bv);
+    if (LDA_) bA[RL] = lds_operand(bl, (s + 3) * 2048);
+    if (LDB_) bB[RL] = lds_operand(bl, 1024 + (s + 1) * 2048);
+    skew_mfmas<NFT, R>(acc, wA, wB, bA, bB);
     constexpr int NM = 8 * NFT;
-    constexpr int NV = LDW ? NFT : 0, ND = (LDA ? 1 : 0) + (LDB ? 1 : 0);
+    constexpr int NV = LDW_ ? NFT : 0, ND = (LDA_ ? 1 : 0) + (LDB_ ? 1 : 0);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -425,139 +502,198 @@ __device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], const f32x4 (&
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// A one-tile stage (4*NFT MFMAs) with one piece of the other tile's epilogue behind every MFMA.
-//   TILE: the tile whose MFMAs run (0 = A at the head of a layer, 1 = B at its tail); the epilogue is the other's.
-//   STORE false: piece = leaky-ReLU of one register quad; true: piece = its ds_write_b128.
-template <int NFT, int R, int TILE, bool STORE, bool FIRST>
-__device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wt)[NFT],
-                                                const f32x4 (&bA)[6], const f32x4 (&bB)[6],
-                                                const f32x16 (&bv)[NFT], float alpha, char* st_base) {
+// A one-tile stage: the 4*NFT MFMAs of tile TILE on one k-group (weights wt, operand b); behind(idx) issues the memory
+// instructions that go behind MFMA idx (stores of the other tile, operand and bias requests), pinned by sched_barriers.
+template <int NFT, int TILE, class Behind>
+__device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wt)[NFT], const f32x4& b,
+                                                Behind&& behind) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
-            const float b = (TILE == 0) ? bA[R][e] : bB[R][e];
-            acc[ft][TILE] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ft][e], b,
-                                                                 (FIRST && e == 0) ? bv[ft] : acc[ft][TILE], 0, 0, 0);
+            acc[ft][TILE] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ft][e], b[e], acc[ft][TILE], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const int idx = e * NFT + ft;
-            if (STORE) store_quad<NFT>(acc, 1 - TILE, idx, st_base);
-            else lrelu_quad(acc[idx >> 2][1 - TILE], idx & 3, alpha);
+            behind(e * NFT + ft);
             __builtin_amdgcn_sched_barrier(0);
         }
 }
 
 // One hidden layer with K = 8*NKG.  The weights of its k-groups 0..2 live in wh (outside the ring), so that the NEXT
 // layer's can be requested as early as stage NKG-3 — two thousand cycles before they are used.  On entry: wh holds
-// (requests for) this layer's k-groups 0..2, bv its bias; tile A's input image is published; acc[.][1] holds the PREVIOUS
-// layer's tile-B pre-activations, not yet stored, and every wave is done reading tile B's image.  On return the same
-// holds one layer on (wn / bias_n = the next layer's weights and bias; when there is none the caller passes this
-// layer's again and ignores the result).
+// (requests for) this layer's k-groups 0..2, bA[0..2] (requests for) tile A's operands of k-groups 0..2, acc[.][0]
+// (requests for) this layer's bias; tile A's input image is published; acc[.][1] holds the PREVIOUS layer's tile-B
+// activations, not yet stored, and every wave is done reading tile B's image.  On return the same holds one layer on
+// (wn / bias_n = the next layer's weights and bias; when there is none the caller passes this layer's again and
+// ignores the result).
 template <int NFT, int NKG>
-__device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x16 (&bv)[NFT],
-                                           const WSrc& wl, const WSrc& wn, const float* bias_n, int wstride,
-                                           const char* bl, char* st_base, float alpha, int wave, int lane ST_PARAM) {
+__device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x4 (&bA)[6],
+                                           const WSrc& wl, const WSrc& wn, const BiasSrc& bias, const BiasSrc& bias_n,
+                                           int wstride, const LdsBase& bl, char* st_base, float alpha ST_PARAM) {
     static_assert((NKG + 2) % 6 == 0 && NKG >= 16, "ring of 6 needs NKG + 2 to be a multiple of 6");
-    f32x4 w[6][NFT], bA[6], bB[6];
-    bA[0] = *(const f32x4*)(bl);
-    bA[1] = *(const f32x4*)(bl + 2048);
-    bA[2] = *(const f32x4*)(bl + 4096);
-    // ---- stage 0: A only; previous layer's tile B activated in the shadow --------------------------------
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) w[3][ft] = wload(wl, 3, wstride, ft);
-    bA[3] = *(const f32x4*)(bl + 3 * 2048);
-    __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 0, 0, false, true>(acc, wh[0], bA, bB, bv, alpha, st_base);
-    // ---- stage 1: A only; previous layer's tile B stored in the shadow -----------------------------------
-#pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) w[4][ft] = wload(wl, 4, wstride, ft);
-    bA[4] = *(const f32x4*)(bl + 4 * 2048);
-    __builtin_amdgcn_sched_barrier(0);
-    skew_edge_stage<NFT, 1, 0, true, false>(acc, wh[1], bA, bB, bv, alpha, st_base);
-    ST(2)
-    __syncthreads();   // tile B's image is published
+    f32x4 w[6][NFT], bB[6];
+    // ---- stage 0: A only; previous layer's tile B stored in the shadow; requests w[3], bA[3] ---------------------
+    // (this layer's bias goes into tile B's accumulators BLAG quads behind the stores that empty them)
+    skew_edge_stage<NFT, 0>(acc, wh[0], bA[0], [&](int idx) {
+        if (idx < NFT) w[3][idx] = wload(wl, 3, wstride, idx);
+        if (idx == NFT) bA[3] = lds_operand(bl, 3 * 2048);
+        store_quad<NFT>(acc, 1, idx, st_base);
+        if (idx >= blag<NFT>()) bias_quad<NFT, 1>(acc, bias, idx - blag<NFT>());
+    });
+    ST(8)
+    __syncthreads();   // P: tile B's image is published
     ST(3)
-    bB[2] = *(const f32x4*)(bl + 1024);
-    bB[3] = *(const f32x4*)(bl + 1024 + 2048);
-    bB[4] = *(const f32x4*)(bl + 1024 + 4096);
-    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage 1: A only; requests w[4], bA[4], bB[2..4] -------------------------------------------------------
+    skew_edge_stage<NFT, 0>(acc, wh[1], bA[1], [&](int idx) {
+        if (idx < NFT) w[4][idx] = wload(wl, 4, wstride, idx);
+        if (idx == 0) bA[4] = lds_operand(bl, 4 * 2048);
+        if (idx == 1) bB[2] = lds_operand(bl, 1024);
+        if (idx == 2) bB[3] = lds_operand(bl, 1024 + 2048);
+        if (idx == 3) bB[4] = lds_operand(bl, 1024 + 4096);
+        if (idx < blag<NFT>()) bias_quad<NFT, 1>(acc, bias, 4 * NFT - blag<NFT>() + idx);
+    });
+    ST(9)
     // ---- stages 2..5: A on wh[2], w[3..5]; B on wh[0..2], w[3] ------------------------------------------------
-    skew_stage<NFT, 2, true, true, true, true>(acc, wh[2], wh[0], w[5], bA, bB, bv, wl, wstride, 5, bl, 2);
-    // Keep the bias registers alive past tile B's first MFMA: were it their last use, hipcc would accumulate B in place
-    // in them, the roles of "bias" and "tile B's accumulators" would swap every layer, and the layer loop would pay for
-    // it with 64 register moves in the middle of the last stage's MFMA chain plus 52 on the back edge.
+    skew_stage<NFT, 2, true, true, true>(acc, wh[2], wh[0], w[5], bA, bB, wl, wstride, 5, bl, 2);
+    skew_stage<NFT, 3, true, true, true>(acc, w[3], wh[1], w[0], bA, bB, wl, wstride, 6, bl, 3);
+    skew_stage<NFT, 4, true, true, true>(acc, w[4], wh[2], w[1], bA, bB, wl, wstride, 7, bl, 4);
+    skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, wl, wstride, 8, bl, 5);
+    // ---- stages 6 .. NKG-5, fully unrolled: every LDS offset is an immediate, every weight offset a scalar ------------
 #pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) asm volatile("" ::"v"(bv[ft]));
-    skew_stage<NFT, 3, true, true, true>(acc, w[3], wh[1], w[0], bA, bB, bv, wl, wstride, 6, bl, 3);
-    skew_stage<NFT, 4, true, true, true>(acc, w[4], wh[2], w[1], bA, bB, bv, wl, wstride, 7, bl, 4);
-    skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, bv, wl, wstride, 8, bl, 5);
-    // ---- stages 6 .. NKG-5 -----------------------------------------------------------------------------------
-#pragma unroll 1
     for (int s = 6; s < NKG - 4; s += 6) {
-        skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, bv, wl, wstride, s + 3, bl, s);
-        skew_stage<NFT, 1, true, true, true>(acc, w[1], w[5], w[4], bA, bB, bv, wl, wstride, s + 4, bl, s + 1);
-        skew_stage<NFT, 2, true, true, true>(acc, w[2], w[0], w[5], bA, bB, bv, wl, wstride, s + 5, bl, s + 2);
-        skew_stage<NFT, 3, true, true, true>(acc, w[3], w[1], w[0], bA, bB, bv, wl, wstride, s + 6, bl, s + 3);
-        skew_stage<NFT, 4, true, true, true>(acc, w[4], w[2], w[1], bA, bB, bv, wl, wstride, s + 7, bl, s + 4);
-        skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, bv, wl, wstride, s + 8, bl, s + 5);
+        skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, wl, wstride, s + 3, bl, s);
+        skew_stage<NFT, 1, true, true, true>(acc, w[1], w[5], w[4], bA, bB, wl, wstride, s + 4, bl, s + 1);
+        skew_stage<NFT, 2, true, true, true>(acc, w[2], w[0], w[5], bA, bB, wl, wstride, s + 5, bl, s + 2);
+        skew_stage<NFT, 3, true, true, true>(acc, w[3], w[1], w[0], bA, bB, wl, wstride, s + 6, bl, s + 3);
+        skew_stage<NFT, 4, true, true, true>(acc, w[4], w[2], w[1], bA, bB, wl, wstride, s + 7, bl, s + 4);
+        skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, wl, wstride, s + 8, bl, s + 5);
     }
-    // ---- stages NKG-4 .. NKG-1: this layer's last requests, then the next layer's first k-groups and bias -------
-    skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, bv, wl, wstride, NKG - 1, bl, NKG - 4);
-    skew_stage<NFT, 1, true, false, true>(acc, w[1], w[5], wh[0], bA, bB, bv, wn, wstride, 0, bl, NKG - 3);
-    skew_stage<NFT, 2, true, false, true>(acc, w[2], w[0], wh[1], bA, bB, bv, wn, wstride, 1, bl, NKG - 2);
-    load_bias<NFT>(bv, bias_n, wave, lane);
-    skew_stage<NFT, 3, true, false, false>(acc, w[3], w[1], wh[2], bA, bB, bv, wn, wstride, 2, bl, NKG - 1);
-    // ---- stage NKG: B only; tile A activated in the shadow ---------------------------------------------------
-    skew_edge_stage<NFT, 4, 1, false, false>(acc, w[2], bA, bB, bv, alpha, st_base);
+    // ---- stages NKG-4 .. NKG-1: this layer's last requests, then the next layer's first k-groups -------------------
+    skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, wl, wstride, NKG - 1, bl, NKG - 4);
+    skew_stage<NFT, 1, true, false, true>(acc, w[1], w[5], wh[0], bA, bB, wn, wstride, 0, bl, NKG - 3);
+    skew_stage<NFT, 2, true, false, true>(acc, w[2], w[0], wh[1], bA, bB, wn, wstride, 1, bl, NKG - 2);
+    skew_stage<NFT, 3, true, false, false>(acc, w[3], w[1], wh[2], bA, bB, wn, wstride, 2, bl, NKG - 1);
     ST(5)
-    __syncthreads();   // every wave is done reading tile A's image
+    __syncthreads();   // Q: every wave has read all of tile A's image (its last operand fed stage NKG-1)
     ST(4)
-    // ---- stage NKG+1: B only; tile A stored in the shadow ----------------------------------------------------
-    skew_edge_stage<NFT, 5, 1, true, false>(acc, w[3], bA, bB, bv, alpha, st_base);
-    ST(5)
-    __syncthreads();   // tile A's image is published; every wave is done reading tile B's
+    lrelu_tile<NFT, 0>(acc, alpha);
+    ST(12)
+    // ---- stage NKG: B only; tile A stored in the shadow ------------------------------------------------------
+    //      (the next layer's bias goes into tile A's accumulators BLAG quads behind the stores that empty them)
+    skew_edge_stage<NFT, 1>(acc, w[2], bB[4], [&](int idx) {
+        store_quad<NFT>(acc, 0, idx, st_base);
+        if (idx >= blag<NFT>()) bias_quad<NFT, 0>(acc, bias_n, idx - blag<NFT>());
+    });
+    ST(10)
+    __syncthreads();   // R: tile A's image is published
     ST(4)
+    // ---- stage NKG+1: B only; requests the next layer's tile-A operands of k-groups 0..2 ---------------------------
+    skew_edge_stage<NFT, 1>(acc, w[3], bB[5], [&](int idx) {
+        if (idx < 3) bA[idx] = lds_operand(bl, idx * 2048);
+        if (idx < blag<NFT>()) bias_quad<NFT, 0>(acc, bias_n, 4 * NFT - blag<NFT>() + idx);
+    });
+    ST(11)
+    __syncthreads();   // S: every wave has read all of tile B's image
+    ST(4)
+    lrelu_tile<NFT, 1>(acc, alpha);
+    ST(13)
 }
 
-// All hidden layers after layer 0.  On entry acc holds layer 0's pre-activations of both tiles (bias included); on
-// return the last hidden layer's activations are in the image, the closing barrier still to come (the caller
-// requests the output layer's weights first).
+// Operands of a pass that do not depend on its samples — layer 0's bias (straight into both tiles' accumulators) and
+// its first weights — requested BEFORE the pass's samples are drawn, so that their round trip (they have been evicted
+// from L2 by the 9 MB of weights streamed since the previous pass) hides behind the sampler.
 template <int HID>
-__device__ __forceinline__ void hidden_skewed(const MlpArgs& m, f32x16 (&acc)[HID / 128][2], f32x16 (&bv)[HID / 128],
-                                              char* act, int wave, int lane ST_PARAM) {
+struct MlpPre {
+    f32x16 acc[HID / 128][2];
+    f32x4 a[HID / 128];
+};
+template <int HID>
+__device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID>& pre, int wave, int lane) {
+    constexpr int NFT = HID / 128, FTT = HID / 32;
+    const BiasSrc b0 = make_bias(m.bp[0], (32 * wave * NFT + 4 * (lane >> 5)) * 4);
+    const WSrc w0 = make_wsrc(m.wp[0] + (wave * NFT) * 256, lane);
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) pre.a[ft] = wload(w0, 0, FTT * 64, ft);
+#pragma unroll
+    for (int idx = 0; idx < 4 * NFT; ++idx) { bias_quad<NFT, 0>(pre.acc, b0, idx); bias_quad<NFT, 1>(pre.acc, b0, idx); }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Layer 0 and all hidden layers after it.  On return the last hidden layer's activations are in the image, the
+// closing barrier still to come (the caller requests the output layer's weights first).
+// Layer 0 (K = k0, a few k-groups) is the same dance without the skew: all k-groups but the last for both tiles, then
+// the last one: tile A's MFMAs, A's leaky-ReLU cluster, tile B's MFMAs with A's stores behind them, barrier, B's cluster.
+template <int HID>
+__device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID>& pre, const char* x0, char* act, int wave,
+                                              int lane ST_PARAM) {
     constexpr int NFT = HID / 128, FTT = HID / 32, NKG = HID / 8;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
+    const int nkg0 = m.k0 >> 3;
     char* st_base = act + act_off<64>(4 * wave * NFT, j, h);
-    const char* bl = act + act_off<64>(0, j, h);
-    f32x4 wh[3][NFT];
+    const LdsBase bl = make_lds_base(act + act_off<64>(0, j, h));
+    const char* xlp = x0 + act_off<64>(0, j, h);
+    const int bias_voff = (32 * wave * NFT + 4 * h) * 4;
+    f32x16 (&acc)[NFT][2] = pre.acc;
+    f32x4 wh[3][NFT], bA[6];
+    const WSrc w0 = make_wsrc(m.wp[0] + (wave * NFT) * 256, lane);
     WSrc wl = make_wsrc(m.wp[nhid > 1 ? 1 : 0] + (wave * NFT) * 256, lane);
+    {   // ---- layer 0 (bias and the first weights: skew_prefetch) ----
+        f32x4 (&a)[NFT] = pre.a;
+        f32x4 bx[2];
+        const BiasSrc b1 = make_bias(m.bp[nhid > 1 ? 1 : 0], bias_voff);
+#pragma unroll 1
+        for (int kg = 0; kg + 1 < nkg0; ++kg) {
+            if (kg > 0) {
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) a[ft] = wload(w0, kg, FTT * 64, ft);
+            }
+            bx[0] = *(const f32x4*)(xlp + kg * 2048);
+            bx[1] = *(const f32x4*)(xlp + 1024 + kg * 2048);
+            skew_edge_stage<NFT, 0>(acc, a, bx[0], [](int) {});
+            skew_edge_stage<NFT, 1>(acc, a, bx[1], [](int) {});
+        }
+        if (nkg0 > 1) {
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) a[ft] = wload(w0, nkg0 - 1, FTT * 64, ft);
+        }
+        bx[0] = *(const f32x4*)(xlp + (nkg0 - 1) * 2048);
+        bx[1] = *(const f32x4*)(xlp + 1024 + (nkg0 - 1) * 2048);
+        skew_edge_stage<NFT, 0>(acc, a, bx[0], [](int) {});
+        // layer 1's first weights are requested only now, behind everything layer 0 waits for; they fly during the cluster
+        if (nhid > 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) wh[g][ft] = wload(wl, g, FTT * 64, ft);
+        }
+        lrelu_tile<NFT, 0>(acc, m.alpha);
+        // (layer 1's bias goes into tile A's accumulators BLAG quads behind the stores that empty them; harmless if
+        // there is no layer 1)
+        skew_edge_stage<NFT, 1>(acc, a, bx[1], [&](int idx) {
+            store_quad<NFT>(acc, 0, idx, st_base);
+            if (idx >= blag<NFT>()) bias_quad<NFT, 0>(acc, b1, idx - blag<NFT>());
+        });
+#pragma unroll
+        for (int i = 0; i < blag<NFT>(); ++i) bias_quad<NFT, 0>(acc, b1, 4 * NFT - blag<NFT>() + i);
+    }
+    __syncthreads();   // tile A's image is published
     if (nhid > 1) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) wh[g][ft] = wload(wl, g, FTT * 64, ft);
-        load_bias<NFT>(bv, m.bp[1], wave, lane);
+        bA[0] = lds_operand(bl, 0);
+        bA[1] = lds_operand(bl, 2048);
+        bA[2] = lds_operand(bl, 4096);
     }
-    // layer 0's tile A (nothing to hide behind yet)
-#pragma unroll
-    for (int idx = 0; idx < 4 * NFT; ++idx) {
-        lrelu_quad(acc[idx >> 2][0], idx & 3, m.alpha);
-        store_quad<NFT>(acc, 0, idx, st_base);
-    }
-    __syncthreads();
+    lrelu_tile<NFT, 1>(acc, m.alpha);
+    ST(1)
     for (int l = 1; l < nhid; ++l) {
         const int ln = (l + 1 < nhid) ? l + 1 : l;
         const WSrc wn = make_wsrc(m.wp[ln] + (wave * NFT) * 256, lane);
-        skew_layer<NFT, NKG>(acc, wh, bv, wl, wn, m.bp[ln], FTT * 64, bl, st_base, m.alpha, wave, lane ST_ARG);
+        skew_layer<NFT, NKG>(acc, wh, bA, wl, wn, make_bias(m.bp[l], bias_voff), make_bias(m.bp[ln], bias_voff),
+                             FTT * 64, bl, st_base, m.alpha ST_ARG);
         wl = wn;
     }
-    // the last hidden layer's tile B
+    // the last hidden layer's tile B (already activated)
 #pragma unroll
-    for (int idx = 0; idx < 4 * NFT; ++idx) {
-        lrelu_quad(acc[idx >> 2][1], idx & 3, m.alpha);
-        store_quad<NFT>(acc, 1, idx, st_base);
-    }
+    for (int idx = 0; idx < 4 * NFT; ++idx) store_quad<NFT>(acc, 1, idx, st_base);
 }
 
 // Output layer for NT feature tiles, K split over the four waves; partial sums go to
@@ -626,30 +762,39 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
 // Runs the MLP on the MS samples whose (padded) inputs sit in the x0 image.  On return
 // part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 256 threads.
+// pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
 template <int HID, int NST, bool JVP = false>
-__device__ __forceinline__ void mlp_core(const MlpArgs& m, char* x0, char* act, int wave, int lane ST_PARAM) {
+constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP && ((HID / 8 + 2) % 6 == 0); }
+
+template <int HID, int NST, bool JVP = false>
+__device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID>& pre, int wave, int lane) {
+    if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID>(m, pre, wave, lane);
+}
+
+template <int HID, int NST, bool JVP = false>
+__device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID>& pre, char* x0, char* act, int wave,
+                                         int lane ST_PARAM) {
     constexpr int NFT = HID / 128;
     constexpr int FTT = HID / 32;
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
-    f32x16 acc[NFT][NST];
-    f32x16 bv[NFT];
-    load_bias<NFT>(bv, m.bp[0], wave, lane);
-    gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
-                                    x0 + act_off<MS>(0, j, h), bv);
     const int nhid = m.n_layers - 1;
     constexpr int KQ = HID / 32;        // k-groups per wave in the output layer
     const bool small_out = (NST == 2) && m.wsmall != nullptr;
     f32x4 wsm[2 * KQ];
-    constexpr bool SKEWED = (NST == 2) && !JVP && ((HID / 8 + 2) % 6 == 0);
+    constexpr bool SKEWED = mlp_is_skewed<HID, NST, JVP>();
     if constexpr (SKEWED) {
-        ST(1)
-        hidden_skewed<HID>(m, acc, bv, act, wave, lane ST_ARG);
+        hidden_skewed<HID>(m, pre, x0, act, wave, lane ST_ARG);
         ST(1)
         if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
         __syncthreads();
         ST(1)
     } else {
+        f32x16 acc[NFT][NST];
+        f32x16 bv[NFT];
+        load_bias<NFT>(bv, m.bp[0], wave, lane);
+        gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
+                                        x0 + act_off<MS>(0, j, h), bv);
         // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
         constexpr bool ACT0 = (NST == 2) && !JVP;
         if constexpr (ACT0) {
@@ -874,7 +1019,7 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
 
 #ifdef RT_STAMPS
     Stamps st;
-    for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+    for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
     st.t = __builtin_amdgcn_s_memtime();
 #endif
     // contiguous block of work units per workgroup: every workgroup gets the same mix of chunk sizes
@@ -899,6 +1044,8 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
         for (int64_t sb = s_begin; sb < s_end; sb += MS) {
             const int64_t si = sb + s;           // this thread's sample index
             ST(7)
+            MlpPre<HID> pre;
+            mlp_prefetch<HID, NST>(m, pre, wave, lane);
             // ---- A. proposal samples -> x0 image --------------------------------------------------
             if (GIVEN) {
                 if (si < s_end) {
@@ -918,7 +1065,7 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             __syncthreads();
             ST(0)
             // ---- B. G forward ---------------------------------------------------------------------
-            mlp_core<HID, NST>(m, x0, act, wave, lane ST_ARG);
+            mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
             // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
             double se = 0.0;
             for (int d = p; d < dy; d += NP) {
@@ -971,8 +1118,11 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
         }
     }
 #ifdef RT_STAMPS
+#if RT_STAMPS == 2
+    st.acc[0] = __builtin_amdgcn_s_memtime() - st.t;
+#endif
     if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[wave * 8 + i], st.acc[i]);
+        for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[wave * NSTAMP + i], st.acc[i]);
 #endif
 }
 
@@ -1021,9 +1171,11 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
                 (row < N) ? in[row * m.in_dim + d] : 0.0f;
         __syncthreads();
 #ifdef RT_STAMPS
-        Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+        Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
-        mlp_core<HID, NST>(m, x0, act, wave, lane ST_ARG);
+        MlpPre<HID> pre;
+        mlp_prefetch<HID, NST>(m, pre, wave, lane);
+        mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
         if (row < N)
             for (int d = ph; d < m.out_dim; d += NP) out[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
     }
@@ -1065,9 +1217,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_jvp_kernel(const MlpArgs m, cons
         }
         __syncthreads();
 #ifdef RT_STAMPS
-        Stamps st; st.t = 0; for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+        Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
-        mlp_core<HID, 2, true>(m, x0, act, wave, lane ST_ARG);
+        MlpPre<HID> pre;
+        mlp_core<HID, 2, true>(m, pre, x0, act, wave, lane ST_ARG);
         if (row < N) {
             if (sl < 32) {
                 if (dir == 0 && yout)
@@ -1624,13 +1777,13 @@ int rt_reset_counters(rt_ctx* ctx) {
 }
 
 #ifdef RT_STAMPS
-int rt_debug_stamps(rt_ctx* ctx, unsigned long long* out32, int reset) {
-    if (!ctx || !out32) return RT_EINVAL;
+int rt_debug_stamps(rt_ctx* ctx, unsigned long long* out48, int reset) {
+    if (!ctx || !out48) return RT_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    HIPCHK(ctx, hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4 * NSTAMP));
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[4 * NSTAMP] = {0};
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
     }
     return RT_OK;

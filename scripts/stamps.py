@@ -14,7 +14,7 @@ eng = _lib.Engine(0)
 eng.set_mlp(0, g.weights, g.biases); eng.set_mlp(1, h.weights, h.biases)
 y = np.random.RandomState(1).standard_normal((2048, dy)); xh = eng.mlp_forward(1, y.astype(np.float32))
 lib = _lib.load()
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 56)()
 eng.is_estimate(y, xh, 6400, 0.1, 0.5)
 lib.rt_debug_stamps(eng._h, buf, 1)
 eng.reset_counters()
@@ -22,12 +22,13 @@ eng.is_estimate(y, xh, 6400, 0.1, 0.5)
 c = eng.counters()
 lib.rt_debug_stamps(eng._h, buf, 1)
 # plain schedule (widths 256/1024): 2 = wait-all-read barrier, 3 = store_act, 4 = post-store barrier, 5 = hidden gemm
-# skewed schedule (widths 128/512):  1 also holds the first / last half-epilogues, 2 = head stages 0-1 (A MFMAs +
-# B's epilogue), 3 = barrier before stage 2, 4 = the two barriers around stage NKG+1, 5 = stages 2 .. NKG+1
-names = ["sample+barrier", "layer0 + unhidden half-epilogues", "head stages (skewed) / wait-all-read barrier",
-         "barrier after head (skewed) / store_act", "tail barriers (skewed) / post-store barrier",
-         "hidden MFMA stages", "last layer", "score+lse"]
-a = np.array(list(buf), dtype=np.float64).reshape(4, 8)
+# skewed schedule (widths 128/512): 1 = layer 0 and the last tile-B stores, 3 = barrier P, 4 = barriers Q, R, S,
+# 5 = steady stages 2 .. NKG-1, 8-11 = the four one-tile edge stages, 12 / 13 = the leaky-ReLU clusters of A / B
+names = ["sample+barrier", "layer 0 + last B stores", "wait-all-read barrier (plain)",
+         "barrier P (skewed) / store_act", "barriers Q R S (skewed) / post-store barrier",
+         "steady MFMA stages", "last layer", "score+lse", "stage 0 (A + B's stores)", "stage 1 (A)",
+         "stage NKG (B + A's stores)", "stage NKG+1 (B)", "lrelu cluster A", "lrelu cluster B"]
+a = np.array(list(buf), dtype=np.float64).reshape(4, 14)
 print("kernel ms", c["kernel_ms"], "TF", c["flops"] / c["kernel_ms"] / 1e9)
 for w in range(4):
     tot = a[w].sum()
