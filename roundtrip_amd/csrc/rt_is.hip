@@ -383,7 +383,8 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
 // Every barrier has MFMAs in flight or a VALU cluster next to it, and no operand read waits on one.
 // Every accumulator sees its k's in the same order as in the plain schedule, so results are bit-identical.
 // Ring slots: weights of k-group g in w[g % 6]; A's operand of k-group g in bA[g % 6]; B's in bB[(g + 2) % 6];
-// all three are requested three stages before their first use.  Needs (NKG + 2) % 6 == 0: widths 128 and 512.
+// all three are requested three stages before their first use.  The stages are unrolled at compile time (skew_steady),
+// so a slot is a fixed register and any NKG >= 8 works: widths 128, 256 and 512.
 // ----------------------------------------------------------------------------------------------
 // LDS operand reads of the skewed schedule: byte offset `off` from this lane's base bl.  ds_read_b128 carries a 16-bit
 // immediate offset; with a second base at +64 KB every (compile-time) offset is an immediate and the fully unrolled
@@ -468,16 +469,17 @@ __device__ __forceinline__ void skew_mfmas(f32x16 (&acc)[NFT][2], const f32x4 (&
 // A steady stage s (ring position R = s % 6): requests the operands of three stages ahead, runs both tiles' MFMAs,
 // and pins one memory instruction behind each of the first MFMAs (see pipe_stage).
 //   wA / wB: the weights A and B use in this stage (ring slots, or the layer's first three k-groups in wh)
-//   wld:     where the LDW request goes (ring slot (R+3)%6, or the NEXT layer's wh) and from which source / k-group
-template <int NFT, int R, bool LDW, bool LDA, bool LDB>
+//   wld:     where the weight request goes (ring slot (R+3)%6, or the NEXT layer's wh) and from which source / k-group
+//   LDA/LDB: whether tile A / tile B still has an operand to request (not in the layer's last stages)
+template <int NFT, int R, bool LDA, bool LDB>
 __device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], const f32x4 (&wA)[NFT], const f32x4 (&wB)[NFT],
                                            f32x4 (&wld)[NFT], f32x4 (&bA)[6], f32x4 (&bB)[6],
                                            const WSrc& wl, int wstride, int kgw, const LdsBase& bl, int s) {
     constexpr int RL = (R + 3) % 6;
 #ifdef RT_ABL   // timing ablation (diagnostic builds only; results are garbage): 1 = no weight loads, 2 = no LDS reads
-    constexpr bool LDW_ = LDW && !(RT_ABL & 1), LDA_ = LDA && !(RT_ABL & 2), LDB_ = LDB && !(RT_ABL & 2);
+    constexpr bool LDW_ = !(RT_ABL & 1), LDA_ = LDA && !(RT_ABL & 2), LDB_ = LDB && !(RT_ABL & 2);
 #else
-    constexpr bool LDW_ = LDW, LDA_ = LDA, LDB_ = LDB;
+    constexpr bool LDW_ = true, LDA_ = LDA, LDB_ = LDB;
 #endif
     if (LDW_) {
 #pragma unroll
@@ -500,6 +502,33 @@ __device__ __forceinline__ void skew_stage(f32x16 (&acc)[NFT][2], const f32x4 (&
     }
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - ND, 0);
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// The weights of k-group G of the current layer: its first three live in wh, the others in ring slot G % 6.
+template <int G, int NFT>
+__device__ __forceinline__ f32x4 (&wslot(f32x4 (&wh)[3][NFT], f32x4 (&w)[6][NFT]))[NFT] {
+    if constexpr (G < 3) return wh[G];
+    else return w[G % 6];
+}
+
+// Steady stages S .. NKG-1, unrolled at compile time: every LDS offset is an immediate, every weight offset a scalar,
+// every ring slot a fixed register.  Stage S requests the operands of stage S+3; once those belong to the next layer
+// (S+3 >= NKG) only that layer's first weights are requested, into wh.
+template <int NFT, int NKG, int S>
+__device__ __forceinline__ void skew_steady(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x4 (&w)[6][NFT],
+                                            f32x4 (&bA)[6], f32x4 (&bB)[6], const WSrc& wl, const WSrc& wn,
+                                            int wstride, const LdsBase& bl) {
+    if constexpr (S < NKG) {
+        constexpr int KA = S + 3;
+        constexpr bool NEXT = KA >= NKG;
+        if constexpr (NEXT)
+            skew_stage<NFT, S % 6, false, (S + 1 < NKG)>(acc, wslot<S, NFT>(wh, w), wslot<S - 2, NFT>(wh, w),
+                                                         wh[KA - NKG], bA, bB, wn, wstride, KA - NKG, bl, S);
+        else
+            skew_stage<NFT, S % 6, true, true>(acc, wslot<S, NFT>(wh, w), wslot<S - 2, NFT>(wh, w), w[KA % 6], bA, bB,
+                                               wl, wstride, KA, bl, S);
+        skew_steady<NFT, NKG, S + 1>(acc, wh, w, bA, bB, wl, wn, wstride, bl);
+    }
 }
 
 // A one-tile stage: the 4*NFT MFMAs of tile TILE on one k-group (weights wt, operand b); behind(idx) issues the memory
@@ -529,7 +558,7 @@ template <int NFT, int NKG>
 __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x4 (&bA)[6],
                                            const WSrc& wl, const WSrc& wn, const BiasSrc& bias, const BiasSrc& bias_n,
                                            int wstride, const LdsBase& bl, char* st_base, float alpha ST_PARAM) {
-    static_assert((NKG + 2) % 6 == 0 && NKG >= 16, "ring of 6 needs NKG + 2 to be a multiple of 6");
+    static_assert(NKG >= 8, "the next layer's first weights are requested into wh from stage NKG-3 on");
     f32x4 w[6][NFT], bB[6];
     // ---- stage 0: A only; previous layer's tile B stored in the shadow; requests w[3], bA[3] ---------------------
     // (this layer's bias goes into tile B's accumulators BLAG quads behind the stores that empty them)
@@ -552,26 +581,8 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
         if (idx < blag<NFT>()) bias_quad<NFT, 1>(acc, bias, 4 * NFT - blag<NFT>() + idx);
     });
     ST(9)
-    // ---- stages 2..5: A on wh[2], w[3..5]; B on wh[0..2], w[3] ------------------------------------------------
-    skew_stage<NFT, 2, true, true, true>(acc, wh[2], wh[0], w[5], bA, bB, wl, wstride, 5, bl, 2);
-    skew_stage<NFT, 3, true, true, true>(acc, w[3], wh[1], w[0], bA, bB, wl, wstride, 6, bl, 3);
-    skew_stage<NFT, 4, true, true, true>(acc, w[4], wh[2], w[1], bA, bB, wl, wstride, 7, bl, 4);
-    skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, wl, wstride, 8, bl, 5);
-    // ---- stages 6 .. NKG-5, fully unrolled: every LDS offset is an immediate, every weight offset a scalar ------------
-#pragma unroll
-    for (int s = 6; s < NKG - 4; s += 6) {
-        skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, wl, wstride, s + 3, bl, s);
-        skew_stage<NFT, 1, true, true, true>(acc, w[1], w[5], w[4], bA, bB, wl, wstride, s + 4, bl, s + 1);
-        skew_stage<NFT, 2, true, true, true>(acc, w[2], w[0], w[5], bA, bB, wl, wstride, s + 5, bl, s + 2);
-        skew_stage<NFT, 3, true, true, true>(acc, w[3], w[1], w[0], bA, bB, wl, wstride, s + 6, bl, s + 3);
-        skew_stage<NFT, 4, true, true, true>(acc, w[4], w[2], w[1], bA, bB, wl, wstride, s + 7, bl, s + 4);
-        skew_stage<NFT, 5, true, true, true>(acc, w[5], w[3], w[2], bA, bB, wl, wstride, s + 8, bl, s + 5);
-    }
-    // ---- stages NKG-4 .. NKG-1: this layer's last requests, then the next layer's first k-groups -------------------
-    skew_stage<NFT, 0, true, true, true>(acc, w[0], w[4], w[3], bA, bB, wl, wstride, NKG - 1, bl, NKG - 4);
-    skew_stage<NFT, 1, true, false, true>(acc, w[1], w[5], wh[0], bA, bB, wn, wstride, 0, bl, NKG - 3);
-    skew_stage<NFT, 2, true, false, true>(acc, w[2], w[0], wh[1], bA, bB, wn, wstride, 1, bl, NKG - 2);
-    skew_stage<NFT, 3, true, false, false>(acc, w[3], w[1], wh[2], bA, bB, wn, wstride, 2, bl, NKG - 1);
+    // ---- stages 2 .. NKG-1: A and B ------------------------------------------------------------------------------
+    skew_steady<NFT, NKG, 2>(acc, wh, w, bA, bB, wl, wn, wstride, bl);
     ST(5)
     __syncthreads();   // Q: every wave has read all of tile A's image (its last operand fed stage NKG-1)
     ST(4)
@@ -579,7 +590,7 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     ST(12)
     // ---- stage NKG: B only; tile A stored in the shadow ------------------------------------------------------
     //      (the next layer's bias goes into tile A's accumulators BLAG quads behind the stores that empty them)
-    skew_edge_stage<NFT, 1>(acc, w[2], bB[4], [&](int idx) {
+    skew_edge_stage<NFT, 1>(acc, w[(NKG - 2) % 6], bB[NKG % 6], [&](int idx) {
         store_quad<NFT>(acc, 0, idx, st_base);
         if (idx >= blag<NFT>()) bias_quad<NFT, 0>(acc, bias_n, idx - blag<NFT>());
     });
@@ -587,7 +598,7 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     __syncthreads();   // R: tile A's image is published
     ST(4)
     // ---- stage NKG+1: B only; requests the next layer's tile-A operands of k-groups 0..2 ---------------------------
-    skew_edge_stage<NFT, 1>(acc, w[3], bB[5], [&](int idx) {
+    skew_edge_stage<NFT, 1>(acc, w[(NKG - 1) % 6], bB[(NKG + 1) % 6], [&](int idx) {
         if (idx < 3) bA[idx] = lds_operand(bl, idx * 2048);
         if (idx < blag<NFT>()) bias_quad<NFT, 0>(acc, bias_n, 4 * NFT - blag<NFT>() + idx);
     });
@@ -764,7 +775,7 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
 // (bias not yet added).  Must be called by all 256 threads.
 // pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
 template <int HID, int NST, bool JVP = false>
-constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP && ((HID / 8 + 2) % 6 == 0); }
+constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 128, 256, 512
 
 template <int HID, int NST, bool JVP = false>
 __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID>& pre, int wave, int lane) {

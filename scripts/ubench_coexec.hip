@@ -22,7 +22,6 @@ __global__ __launch_bounds__(512) void bench(float* out, int iters, unsigned lon
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float a = threadIdx.x * 1e-3f, b = 1.0f;
     float v[16];
-    float av[4] = {a, a + 1.f, a + 2.f, a + 3.f};
     f32x2 pv[8];
     f32x4 sv = {1.f, 2.f, 3.f, 4.f};
     f32x4 ld[4] = {sv, sv, sv, sv};
@@ -30,21 +29,12 @@ __global__ __launch_bounds__(512) void bench(float* out, int iters, unsigned lon
     for (int i = 0; i < 16; ++i) v[i] = threadIdx.x + i;
     for (int i = 0; i < 8; ++i) pv[i] = f32x2{v[i], v[i + 8]};
     const unsigned lp = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
-    asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_write_b32 a1, %1" ::"v"(a), "v"(b) : "a0", "a1");
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (KIND == 11) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(a), "v"(b));
-            else if (KIND == 12) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "a"(b));
-            else if (KIND == 13) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(a), "a"(b));
-            else if (KIND == 15) asm volatile("v_mfma_f32_32x32x2_f32 %0, a0, %1, %0" : "+v"(acc[i]) : "v"(b));
-            else if (KIND == 16) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, a1, %0" : "+v"(acc[i]) : "v"(a));
-            else if (KIND == 17) asm volatile("v_mfma_f32_32x32x2_f32 %0, a0, a1, %0" : "+v"(acc[i]));
-            else if (KIND == 18) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
-            else if (KIND == 14) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av[i & 3]), "v"(v[i]));
-            else MFMA(i);
+            MFMA(i);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = (i * K + k) & 15;
@@ -110,11 +100,6 @@ int main() {
     hipMalloc(&g_w, (size_t)256 * 512 * 16 + 8192);
     hipMemset(g_w, 0, (size_t)256 * 512 * 16 + 8192);
     run<0, 0>("mfma only", out, cyc);
-    run<0, 15>("mfma, A operand in AGPR", out, cyc);
-    run<0, 16>("mfma, B operand in AGPR", out, cyc);
-    run<0, 17>("mfma, A and B in AGPR", out, cyc);
-    run<0, 18>("mfma, accumulators in AGPRs", out, cyc);
-    run<0, 14>("mfma, varying A/B regs", out, cyc);
     run<1, 7>("global_load_dwordx4", out, cyc);
     run<2, 7>("global_load_dwordx4", out, cyc);
     run<1, 8>("ds_read_b128", out, cyc);
