@@ -29,6 +29,13 @@ class _IsModelBase(object):
     is_seed = 0
     #: shard query points over torch.distributed ranks when a process group is initialised
     shard = True
+    #: where the proposal draws come from.  "philox": the in-kernel counter-based sampler (the fast path).
+    #: "numpy": the reference's own draws — numpy's legacy MT19937 stream seeded with 0, consumed exactly as
+    #: sample_from_qx does (main_density_est.py:267, 310-318: per query point, in order, chisquare(df, S) then
+    #: multivariate_normal(0, scale^2 I, (S,))) — generated on the host and scored by the same kernel
+    #: (rt_is_estimate_given_samples).  With identical weights this reproduces a single-threaded run of the reference
+    #: up to the fp32 rounding of G; it is ~100x slower than "philox" (the host RNG) and exists for validation.
+    is_sampler = "philox"
 
     def _init_engine_state(self, device):
         self._device = device
@@ -77,11 +84,43 @@ class _IsModelBase(object):
             return eng.is_estimate(pts, centres, sample_size, sd, scale, df=df, seed=self.is_seed, log=log,
                                    y_index_base=base)
 
+        if self.is_sampler == "numpy":
+            block = self._reference_draws_block(points, sd, scale, sample_size, df, log)
+        elif self.is_sampler != "philox":
+            raise ValueError("is_sampler must be 'philox' or 'numpy', not %r" % (self.is_sampler,))
         if self.shard and dist.world()[1] > 1:
             return dist.sharded_map(points, block)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
+
+    def _reference_draws_block(self, points, sd, scale, sample_size, df, log):
+        """block(pts, base) for is_sampler == "numpy".  The legacy stream is sequential over ALL query points, so a
+        rank that starts at `base` first consumes (and discards) the draws of the points before it."""
+        eng = self.engine
+        x_dim = self._nets()[0][1].input_dim
+        S = int(sample_size)
+        cov = np.diag(scale ** 2 * np.ones(x_dim))
+        bs = max(1, min(1024, (256 << 20) // (S * x_dim * 8)))   # <= 256 MB of float64 draws per upload
+
+        def draw(rng, centre):
+            # main_density_est.py:315-318 / roundtrip.py:278-280, same calls in the same order
+            z1 = rng.chisquare(df, S) / df
+            z2 = rng.multivariate_normal(np.zeros(x_dim), cov, (S,))
+            return centre + z2 / np.sqrt(z1)[:, None]
+
+        def block(pts, base):
+            rng = np.random.RandomState(0)          # np.random.seed(0) at :267, without clobbering the global generator
+            centres = eng.mlp_forward(_lib.RT_MLP_H, pts.astype(np.float32))
+            for _ in range(base):
+                draw(rng, 0.0)
+            out = np.empty(pts.shape[0], dtype=np.float64)
+            for lo in range(0, pts.shape[0], bs):
+                hi = min(pts.shape[0], lo + bs)
+                xs = np.stack([draw(rng, centres[i].astype(np.float64)) for i in range(lo, hi)])
+                out[lo:hi] = eng.is_estimate_given_samples(pts[lo:hi], centres[lo:hi], xs, sd, scale, df, log=log)
+            return out
+        return block
 
     # ---- the Laplace (closed-form) estimator ----------------------------------------------------------
     def _jacobian(self, latent):

@@ -197,3 +197,42 @@ def test_v2_evaluate_grid_caller(tmp_path):
     assert np.array_equal(np.load("%s/2d_grid_IS_density_pre_at_7.npy" % m.save_dir), want)
     assert np.array_equal(res["px_CF"], m.estimate_px_with_CF(grid, sd_x=0.4, log=False).reshape(n, n))
     assert np.all(np.isfinite(res["px_CF"])) and np.all(res["px_IS"] >= 0)
+
+
+def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path, monkeypatch):
+    """is_sampler = "numpy": numpy's legacy stream seeded with 0, consumed like sample_from_qx (main_density_est.py:267,
+    310-318), scored on the GPU.  The oracle's statement-by-statement restatement of estimate_py_with_IS draws from the
+    same stream (the GLOBAL generator, as the reference does) and runs G in numpy: the two must agree to the fp32
+    rounding of G, for both classes, log and linear, and for a rank that starts in the middle of the stream."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    from oracle import is_ref
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(5)
+    g = Generator(2, 2, "g_net", nb_layers=10, nb_units=512, rng=rng)
+    h = Generator(2, 2, "h_net", nb_layers=10, nb_units=256, rng=rng)
+    m = RoundtripModel(g, h, data="indep_gmm", df=1)
+    m.is_sampler = "numpy"
+    y = np.random.RandomState(6).standard_normal((7, 2)) * 0.3
+    S = 2500
+    state = np.random.get_state()
+    got = m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.5, sample_size=S, log=True, save=False)
+    assert np.array_equal(state[1], np.random.get_state()[1]) and state[2] == np.random.get_state()[2]   # global generator untouched
+    want = is_ref.estimate_py_with_IS(g, h, y, sd_y=0.1, scale=0.5, sample_size=S, df=1, log=True)
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+    lin = m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.5, sample_size=S, log=False, save=False)
+    np.testing.assert_allclose(lin, is_ref.estimate_py_with_IS(g, h, y, sd_y=0.1, scale=0.5, sample_size=S, df=1,
+                                                               log=False), rtol=2e-4)
+    # a block that starts at global index 3 consumes the first three points' draws first
+    blk = m._reference_draws_block(y, 0.1, 0.5, S, 1, True)
+    np.testing.assert_array_equal(blk(y[3:], 3), got[3:])
+    # df = 3 (chisquare with another shape), through the v2 class
+    params = dict(dataset="t", output_dir=str(tmp_path), x_dim=2, z_dim=2, g_units=[512] * 10, e_units=[256] * 10)
+    m2 = Roundtrip(params, timestamp="ref", random_seed=9)
+    m2.is_sampler = "numpy"
+    got3 = m2.estimate_px_with_IS(y, sd_x=0.2, scale=0.3, sample_size=1500, df=3)
+    want3 = is_ref.estimate_py_with_IS(m2.g_net, m2.e_net, y, sd_y=0.2, scale=0.3, sample_size=1500, df=3)
+    np.testing.assert_allclose(got3, want3, rtol=2e-6)
+    m2.is_sampler = "mt"
+    with pytest.raises(ValueError):
+        m2.estimate_px_with_IS(y)
