@@ -1,0 +1,96 @@
+// rt_sampler.hpp — the counter-based proposal sampler (replaces sample_from_qx,
+// /root/reference/main_density_est.py:310-318).  Included by rt_is.hip only.
+#pragma once
+
+// ----------------------------------------------------------------------------------------------
+// Proposal sampler: Philox4x32-10, counter = (sample index, call index, y index lo, y index hi),
+// key = seed.  Call c yields standard normals g[4c .. 4c+3] by two Box-Muller transforms.
+// Integer df = ndf: chi2 = g[0]^2 + .. + g[ndf-1]^2, x_d = xhat_d + scale * g[ndf+d] / sqrt(chi2/df).
+// Non-integer df: chi2 = 2*Gamma(df/2) by Marsaglia-Tsang on call indices >= 0x40000000; x_d uses g[d].
+// ----------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {   // (0,1), 24 bits, never 0 or 1
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u01(b), &sn, &cs);
+    n0 = r * cs;
+    n1 = r * sn;
+}
+
+struct SamplerArgs {
+    uint32_t seed_lo, seed_hi;
+    int ndf;        // df if it is an integer in [1, 32], else 0 (gamma path)
+    float df;
+    float scale;
+};
+
+__device__ float chi2_over_df_gamma(const SamplerArgs& sa, uint32_t i, uint32_t ylo, uint32_t yhi) {
+    // chi2(df)/df with chi2 = 2*Gamma(df/2, 1)  (Marsaglia & Tsang 2000).
+    float shape = 0.5f * sa.df;
+    float boost = 1.0f;
+    uint32_t call = 0x40000000u;
+    if (shape < 1.0f) {
+        const U4 r = philox4x32_10(i, call++, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        boost = powf(u01(r.x), 1.0f / shape);
+        shape += 1.0f;
+    }
+    const float d = shape - (1.0f / 3.0f), c = 1.0f / sqrtf(9.0f * d);
+    float g = d;   // fallback if 64 rejections in a row (probability < 1e-80)
+    for (int it = 0; it < 64; ++it) {
+        const U4 r = philox4x32_10(i, call++, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        float z, unused;
+        box_muller(r.x, r.y, z, unused);
+        float v = 1.0f + c * z;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        const float u = u01(r.z);
+        if (logf(u) < 0.5f * z * z + d - d * v + d * logf(v)) { g = d * v; break; }
+    }
+    return 2.0f * g * boost / sa.df;
+}
+
+// Calls put(d, x_d) for d = 0 .. dx-1 with the proposal sample (yidx, i) around xhat.
+template <typename Put>
+__device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx, uint32_t i,
+                                            const float* xhat, int dx, Put put) {
+    const uint32_t ylo = (uint32_t)yidx, yhi = (uint32_t)(yidx >> 32);
+    float zsum = 0.0f, mult = 0.0f;
+    if (sa.ndf == 0) mult = sa.scale / sqrtf(chi2_over_df_gamma(sa, i, ylo, yhi));
+    const int total = sa.ndf + dx;
+    for (int c = 0; 4 * c < total; ++c) {
+        const U4 r = philox4x32_10(i, (uint32_t)c, ylo, yhi, sa.seed_lo, sa.seed_hi);
+        float n[4];
+        box_muller(r.x, r.y, n[0], n[1]);
+        box_muller(r.z, r.w, n[2], n[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = 4 * c + k;
+            if (g < sa.ndf) {
+                zsum += n[k] * n[k];
+                if (g == sa.ndf - 1) mult = sa.scale / sqrtf(zsum / sa.df);
+            } else if (g < total) {
+                const int d = g - sa.ndf;
+                put(d, xhat[d] + mult * n[k]);
+            }
+        }
+    }
+}
+

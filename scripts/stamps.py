@@ -1,5 +1,5 @@
 """Diagnostic: per-phase cycle shares of the fused kernel (workgroup 0), from a -DRT_STAMPS build.
-Build here:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRT_STAMPS -o build_diag/librt_is_stamps.so roundtrip_amd/csrc/rt_is.hip
+Build here:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-mfma-vgpr-form -DRT_STAMPS -o build_diag/librt_is_stamps.so roundtrip_amd/csrc/rt_is.hip
 Run on the GPU box:  RT_IS_LIB=build_diag/librt_is_stamps.so python scripts/stamps.py [dx dy]
 """
 import ctypes as C, os, sys
