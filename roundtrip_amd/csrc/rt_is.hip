@@ -68,6 +68,7 @@ struct rt_ctx {
     DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
     double flops_acc = 0.0;
     uint64_t evals_acc = 0;
     std::string err;
@@ -167,17 +168,12 @@ int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArg
     return RT_OK;
 }
 
-// Enqueues the fused kernel + finalize.  All pointers are device pointers.
-int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
-               int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
-               uint64_t seed, int log_flag, double* out) {
+// Enqueues one launch of the fused kernel + finalize for N query points whose results go to out[k*out_stride + n].
+// All pointers are device pointers.
+int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
+                     int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
+                     uint64_t seed, int log_flag, double* out, int64_t out_stride) {
     HostMlp& G = ctx->mlp[RT_MLP_G];
-    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
-    if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
-    if (n_sd < 1 || n_sd > RT_MAX_SD || !sd_ys) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
-    for (int k = 0; k < n_sd; ++k)
-        if (!(sd_ys[k] > 0.0) || !isfinite(sd_ys[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
-    if (N == 0) return RT_OK;
     IsArgs a;
     memset(&a, 0, sizeof(a));
     a.g = G.args;
@@ -238,8 +234,36 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     ctx->evals_acc += (uint64_t)N * (uint64_t)S;
     const int fb = 256;
     hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + fb - 1) / fb)), dim3(fb), 0, ctx->stream,
-                       (const double*)a.partial, N, a.nchunks, n_sd, log((double)S), log_flag, out);
+                       (const double*)a.partial, N, a.nchunks, n_sd, log((double)S), log_flag, out, out_stride);
     HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// Validates, then enqueues the estimate as one launch per block of query points: a launch is bounded to
+// ctx->max_launch_evals sample-evals (about 8 s of one MI355X by default), so that a 10^10-eval call (BASELINE config 3's
+// share of one GPU) is a sequence of bounded kernels rather than one that runs for minutes.  Query points are
+// independent and the sampler is keyed by the global index, so the split does not change any draw.
+int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
+               int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
+               uint64_t seed, int log_flag, double* out) {
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
+    if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
+    if (n_sd < 1 || n_sd > RT_MAX_SD || !sd_ys) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
+    for (int k = 0; k < n_sd; ++k)
+        if (!(sd_ys[k] > 0.0) || !isfinite(sd_ys[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
+    if (N == 0) return RT_OK;
+    const int dx = G.args.in_dim, dy = G.args.out_dim;
+    int64_t per = ctx->max_launch_evals / S;
+    if (per < 1) per = 1;
+    const int64_t nblocks = (N + per - 1) / per;
+    per = (N + nblocks - 1) / nblocks;           // balanced blocks
+    for (int64_t n0 = 0; n0 < N; n0 += per) {
+        const int64_t nb = (N - n0 < per) ? N - n0 : per;
+        const int rc = is_enqueue_block(ctx, y + n0 * dy, xhat + n0 * dx, xs ? xs + (size_t)n0 * S * dx : nullptr, nb,
+                                        y_index_base + n0, S, n_sd, sd_ys, scale, df, seed, log_flag, out + n0, N);
+        if (rc) return rc;
+    }
     return RT_OK;
 }
 
@@ -300,6 +324,10 @@ int rt_ctx_create(int device, rt_ctx** out) {
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
     ctx->cu_count = prop.multiProcessorCount;
+    if (const char* v = getenv("RT_IS_MAX_LAUNCH_EVALS")) {
+        const long long n = atoll(v);
+        if (n > 0) ctx->max_launch_evals = n;
+    }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
     *out = ctx;

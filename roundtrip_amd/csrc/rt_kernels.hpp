@@ -181,9 +181,9 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
 #endif
 }
 
-// out[k*N + n] for sd index k: merges the chunks of query point n.
+// out[k*out_stride + n] for sd index k: merges the chunks of query point n (n < N, this launch's block).
 __global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, int n_sd, double logS,
-                                   int log_flag, double* out) {
+                                   int log_flag, double* out, int64_t out_stride) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     for (int k = 0; k < n_sd; ++k) {
@@ -195,7 +195,7 @@ __global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks
         for (int c = 0; c < nchunks; ++c)
             if (p[c * cs] > -INFINITY) t += p[c * cs + 1] * exp(p[c * cs] - M);
         const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
-        out[(int64_t)k * N + n] = log_flag ? lp : exp(lp);
+        out[(int64_t)k * out_stride + n] = log_flag ? lp : exp(lp);
     }
 }
 

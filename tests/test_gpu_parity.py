@@ -223,6 +223,36 @@ def test_sharding_and_chunking_invariance(engine, make_nets):
     np.testing.assert_allclose(one, full[7:8], rtol=1e-13)
 
 
+def test_large_calls_split_into_bounded_launches(engine, make_nets, monkeypatch):
+    """A call above the per-launch bound (2^28 sample-evals by default; RT_IS_MAX_LAUNCH_EVALS, read when a context is
+    created) runs as several launches over blocks of query points.  The split changes no draw and no result: plain,
+    several-sd and given-samples calls agree with the one-launch answers."""
+    gw, gb, hw, hb = make_nets(3, 6)
+    y = np.random.RandomState(15).standard_normal((37, 6)) * 0.1
+    S = 700
+    monkeypatch.setenv("RT_IS_MAX_LAUNCH_EVALS", str(5 * S + 1))            # 5 points per launch: 8 launches, ragged tail
+    small = _lib.Engine(0)
+    try:
+        for e in (engine, small):
+            e.set_mlp(G, gw, gb)
+            e.set_mlp(H, hw, hb)
+        xhat = engine.mlp_forward(H, y.astype(np.float32))
+        engine.reset_counters(); small.reset_counters()
+        one = engine.is_estimate(y, xhat, S, 0.3, 0.1, 1.0, seed=3, y_index_base=11)
+        many = small.is_estimate(y, xhat, S, 0.3, 0.1, 1.0, seed=3, y_index_base=11)
+        assert engine.counters()["launches"] == 1 and small.counters()["launches"] == 8
+        assert small.counters()["sample_evals"] == 37 * S
+        np.testing.assert_allclose(many, one, rtol=1e-13)
+        sds = [0.05, 0.3, 1.0]
+        np.testing.assert_allclose(small.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3),
+                                   engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3), rtol=1e-13)
+        xs = engine.draw_samples(xhat, S, 0.1, 1.0, seed=3).astype(np.float64)
+        np.testing.assert_allclose(small.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False),
+                                   engine.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False), rtol=1e-13)
+    finally:
+        small.close()
+
+
 @pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 129])
 def test_ragged_sample_counts(engine, make_nets, S):
     gw, gb, hw, hb = make_nets(3, 6)
