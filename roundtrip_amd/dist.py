@@ -33,6 +33,10 @@ def world():
 def all_gather_blocks(local, n, device=None):
     """Assembles the full (n,) float64 result from every rank's contiguous block (see shard_bounds).
 
+    device: the HIP device index this rank computes on (the engine's).  Under the "nccl" backend the gather buffers
+    live there — NOT on torch's current device, which is 0 on every rank unless the caller set it, and RCCL refuses
+    two ranks on one GPU.  Ignored under "gloo" (host buffers).
+
     One all_gather of ceil(n / world) float64 per rank — the only collective on the path.  Payloads are tiny
     (1M points = 8 MB in total), so this is latency- not bandwidth-bound; a single direct all-gather is right.
     """
@@ -42,8 +46,12 @@ def all_gather_blocks(local, n, device=None):
     import torch
     import torch.distributed as dist
     per = -(-int(n) // ws)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")
+    elif device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = torch.device("cuda", int(device))
     buf = torch.zeros(per, dtype=torch.float64, device=device)
     loc = torch.as_tensor(np.asarray(local, dtype=np.float64))
     buf[: loc.numel()] = loc.to(device)
@@ -52,7 +60,7 @@ def all_gather_blocks(local, n, device=None):
     return out.cpu().numpy()[:n].copy()
 
 
-def sharded_map(points, fn):
+def sharded_map(points, fn, device=None):
     """Evaluates fn(block, global_index_of_block_start) on this rank's block of `points` and gathers.
 
     fn returns one float64 per row of its block.  With one rank it is simply fn(points, 0)."""
@@ -61,4 +69,4 @@ def sharded_map(points, fn):
     rank, ws = world()
     lo, hi = shard_bounds(n, ws, rank)
     local = fn(points[lo:hi], lo) if hi > lo else np.zeros(0, dtype=np.float64)
-    return all_gather_blocks(local, n)
+    return all_gather_blocks(local, n, device)

@@ -89,7 +89,7 @@ class _IsModelBase(object):
         elif self.is_sampler != "philox":
             raise ValueError("is_sampler must be 'philox' or 'numpy', not %r" % (self.is_sampler,))
         if self.shard and dist.world()[1] > 1:
-            return dist.sharded_map(points, block)
+            return dist.sharded_map(points, block, device=eng.device)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
@@ -160,7 +160,7 @@ class _IsModelBase(object):
             return 1. / (np.sqrt(2 * np.pi) * sd) ** y_dim * sd ** y_dim * np.sqrt(det) * np.exp(-0.5 * c_y)
 
         if self.shard and dist.world()[1] > 1:
-            return dist.sharded_map(points, block)
+            return dist.sharded_map(points, block, device=eng.device)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
@@ -187,7 +187,7 @@ class _IsModelBase(object):
             centres = eng.mlp_forward(_lib.RT_MLP_H, points[lo:hi].astype(np.float32))
             local = eng.is_estimate_multi(points[lo:hi], centres, sample_size, sds, scale, df=df,
                                           seed=self.is_seed, log=log, y_index_base=lo)
-        return np.stack([dist.all_gather_blocks(local[k], points.shape[0]) for k in range(len(sds))])
+        return np.stack([dist.all_gather_blocks(local[k], points.shape[0], device=eng.device) for k in range(len(sds))])
 
 
 class Roundtrip(_IsModelBase):

@@ -236,3 +236,47 @@ def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path,
     m2.is_sampler = "mt"
     with pytest.raises(ValueError):
         m2.estimate_px_with_IS(y)
+
+
+def test_model_level_sharding_two_ranks(tmp_path):
+    """One process per rank (here: two gloo ranks that share HIP device 0; on a node it is one GPU each over RCCL):
+    the drop-in classes shard the query points, every rank returns the FULL result, and it equals the one-process
+    answer bit for bit (contiguous blocks keyed by the global query index) — IS, the several-sd sweep and the
+    Laplace estimator."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    import socket, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ["LOCAL_RANK_SAVED"] = os.environ.get("LOCAL_RANK", "0")
+        import numpy as np
+        import torch.distributed as dist
+        from roundtrip_amd import Generator, RoundtripModel
+        dist.init_process_group("gloo")
+        rng = np.random.RandomState(21)
+        g = Generator(3, 6, "g_net", nb_layers=10, nb_units=512, rng=rng)
+        h = Generator(6, 3, "h_net", nb_layers=10, nb_units=256, rng=rng)
+        m = RoundtripModel(g, h, data="arem", df=1, device=0)        # both ranks on the one GPU of the test box
+        y = np.random.RandomState(22).standard_normal((13, 6)) * 0.1
+        out = dict(IS=m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False),
+                   multi=m._estimate_is_multi(y, [0.05, 0.1], 0.1, 900, 1, True),
+                   CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
+        m.shard = False
+        one = dict(IS=m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False),
+                   multi=m._estimate_is_multi(y, [0.05, 0.1], 0.1, 900, 1, True),
+                   CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
+        for k in out:
+            assert out[k].shape == one[k].shape and np.array_equal(out[k], one[k]), (k, out[k], one[k])
+        dist.barrier(); dist.destroy_process_group()
+        print("rank ok")
+    """ % (root,)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300,
+                         cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert res.stdout.count("rank ok") == 2
