@@ -65,12 +65,14 @@ def test_mlp_forward_heavy_tails_and_specials(engine, make_nets):
     assert not np.isfinite(got[5]).any() and np.isnan(got[6]).all()
 
 
-@pytest.mark.parametrize("hid,nl", [(128, 1), (128, 3), (256, 2), (512, 4)])
-def test_other_depths_and_widths(engine, hid, nl):
+@pytest.mark.parametrize("hid,nl,din", [(128, 1, 3), (128, 3, 3), (256, 2, 3), (512, 4, 3),
+                                        # one hidden layer; input dims that take 2, 3 and 5 k-groups in layer 0
+                                        (512, 1, 12), (256, 1, 8), (256, 3, 16), (512, 2, 40), (128, 2, 20)])
+def test_other_depths_and_widths(engine, hid, nl, din):
     from conftest import glorot
-    ws, bs = glorot([3] + [hid] * nl + [5], 9, 10)
+    ws, bs = glorot([din] + [hid] * nl + [5], 9, 10)
     engine.set_mlp(G, ws, bs)
-    x = np.random.RandomState(1).standard_normal((100, 3)).astype(np.float32)
+    x = np.random.RandomState(1).standard_normal((100, din)).astype(np.float32)
     assert np.array_equal(engine.mlp_forward(G, x), c_oracle.OracleMlp(ws, bs).forward(x, c_oracle.ORDER_KERNEL))
 
 
