@@ -105,6 +105,8 @@ int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);
  *         - sum_d t.logpdf(xhat_d - x_id, df, 0, scale)
  * Reduction (:339-345): log( sum_i exp(v_i) ) - log(S).
  * Samples whose score is not finite carry weight 0.
+ * A call of more than 2^28 sample-evals (N*S; the environment variable RT_IS_MAX_LAUNCH_EVALS, read by rt_ctx_create,
+ * overrides the bound) runs as several kernel launches over blocks of query points; the result is the same.
  */
 int rt_is_estimate(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
                    int64_t S, double sd_y, double scale, double df, uint64_t seed, int log_flag,

@@ -318,3 +318,52 @@ def test_evaluate_callers_host_logic():
     X = np.array([[0.0, 0.1], [3.0, 3.0], [0.2, 0.0], [-4.0, 1.0]])
     prec, py = ev.odd_evaluate(m, X, np.array([0, 1, 0, 1]), 0.1, 0.5)
     assert prec == 1.0 and m.seen["log"] is True
+
+
+def test_reference_draws_mode_host_logic(tmp_path, monkeypatch):
+    """is_sampler = "numpy" on CPU, with a stub in place of the GPU engine: the samples handed to the given-samples
+    entry point are exactly what the oracle's statement-by-statement restatement draws from numpy's GLOBAL generator
+    (seed 0; per point chisquare then multivariate_normal), a rank that starts at index 3 skips the first three points'
+    draws, and the global generator is left alone."""
+    from oracle import is_ref
+    from roundtrip_amd import Generator, RoundtripModel
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(3)
+    g = Generator(2, 3, "g_net", nb_layers=2, nb_units=16, rng=rng)
+    h = Generator(3, 2, "h_net", nb_layers=2, nb_units=16, rng=rng)
+    m = RoundtripModel(g, h, data="t", df=3)
+    y = np.random.RandomState(4).standard_normal((6, 3))
+    S = 50
+    og, oh = is_ref.DenseNet(g.weights, g.biases, g.alpha), is_ref.DenseNet(h.weights, h.biases, h.alpha)   # numpy MLPs
+    want, xs_ref, centres_ref = is_ref.estimate_py_with_IS(og, oh, y, sd_y=0.4, scale=0.2, sample_size=S, df=3,
+                                                            return_samples=True)
+
+    class StubEngine(object):
+        device = 0
+        seen = []
+
+        def mlp_forward(self, which, x):
+            assert which == 1
+            return is_ref.predict(oh, x.astype(np.float64), 2).astype(np.float32)
+
+        def is_estimate_given_samples(self, pts, centres, xs, sd, scale, df, log=True):
+            StubEngine.seen.append(np.array(xs))
+            keep = np.random.get_state()      # the oracle reseeds the global generator (as the reference does); the stub hides that
+            out = is_ref.estimate_py_with_IS(og, oh, pts, sd_y=sd, scale=scale, sample_size=xs.shape[1], df=df, log=log,
+                                             x_samples=xs)
+            np.random.set_state(keep)
+            return out
+
+    m._engine = StubEngine()
+    m._uploaded = {0: (id(g), g.version), 1: (id(h), h.version)}
+    m.is_sampler = "numpy"
+    np.random.seed(77)
+    state = np.random.get_state()
+    got = m.estimate_py_with_IS(y, 0, sd_y=0.4, scale=0.2, sample_size=S, save=False)
+    assert np.array_equal(np.random.get_state()[1], state[1])
+    assert np.array_equal(np.concatenate(StubEngine.seen), xs_ref)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    StubEngine.seen = []
+    tail = m._reference_draws_block(y, 0.4, 0.2, S, 3, True)(y[3:], 3)
+    assert np.array_equal(np.concatenate(StubEngine.seen), xs_ref[3:])
+    np.testing.assert_allclose(tail, want[3:], rtol=1e-12)

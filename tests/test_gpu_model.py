@@ -218,10 +218,12 @@ def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path,
     state = np.random.get_state()
     got = m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.5, sample_size=S, log=True, save=False)
     assert np.array_equal(state[1], np.random.get_state()[1]) and state[2] == np.random.get_state()[2]   # global generator untouched
-    want = is_ref.estimate_py_with_IS(g, h, y, sd_y=0.1, scale=0.5, sample_size=S, df=1, log=True)
+    # the oracle's own numpy networks: a product Generator handed to the oracle would run its forward on the GPU
+    og, oh = is_ref.DenseNet(g.weights, g.biases, g.alpha), is_ref.DenseNet(h.weights, h.biases, h.alpha)
+    want = is_ref.estimate_py_with_IS(og, oh, y, sd_y=0.1, scale=0.5, sample_size=S, df=1, log=True)
     np.testing.assert_allclose(got, want, rtol=2e-6)
     lin = m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.5, sample_size=S, log=False, save=False)
-    np.testing.assert_allclose(lin, is_ref.estimate_py_with_IS(g, h, y, sd_y=0.1, scale=0.5, sample_size=S, df=1,
+    np.testing.assert_allclose(lin, is_ref.estimate_py_with_IS(og, oh, y, sd_y=0.1, scale=0.5, sample_size=S, df=1,
                                                                log=False), rtol=2e-4)
     # a block that starts at global index 3 consumes the first three points' draws first
     blk = m._reference_draws_block(y, 0.1, 0.5, S, 1, True)
@@ -231,7 +233,9 @@ def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path,
     m2 = Roundtrip(params, timestamp="ref", random_seed=9)
     m2.is_sampler = "numpy"
     got3 = m2.estimate_px_with_IS(y, sd_x=0.2, scale=0.3, sample_size=1500, df=3)
-    want3 = is_ref.estimate_py_with_IS(m2.g_net, m2.e_net, y, sd_y=0.2, scale=0.3, sample_size=1500, df=3)
+    want3 = is_ref.estimate_py_with_IS(is_ref.DenseNet(m2.g_net.weights, m2.g_net.biases, m2.g_net.alpha),
+                                       is_ref.DenseNet(m2.e_net.weights, m2.e_net.biases, m2.e_net.alpha), y, sd_y=0.2,
+                                       scale=0.3, sample_size=1500, df=3)
     np.testing.assert_allclose(got3, want3, rtol=2e-6)
     m2.is_sampler = "mt"
     with pytest.raises(ValueError):
