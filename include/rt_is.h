@@ -146,7 +146,10 @@ int rt_mlp_forward_dev(rt_ctx* ctx, int which, const float* in_dev, int64_t N, f
 /* Waits for everything enqueued on the context's stream. */
 int rt_sync(rt_ctx* ctx);
 
-/* Kernel-time / flop counters accumulated since the last rt_reset_counters (waits for the stream). */
+/* Kernel-time / flop counters accumulated since the last rt_reset_counters (waits for the stream).  Every launch of
+ * the fused kernel is bracketed by a pair of HIP events; a context keeps at most 512 pairs and folds them into the
+ * running sum (waiting for the newest one) when that many launches are outstanding, so the asynchronous entry points
+ * block briefly once per 512 launches even if the counters are never read. */
 int rt_get_counters(rt_ctx* ctx, rt_counters* out);
 int rt_reset_counters(rt_ctx* ctx);
 

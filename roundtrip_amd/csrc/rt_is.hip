@@ -68,6 +68,8 @@ struct rt_ctx {
     DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    double ms_harvested = 0.0;              // durations already folded in by harvest_events()
+    uint64_t launches_harvested = 0;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
     double flops_acc = 0.0;
     uint64_t evals_acc = 0;
@@ -76,7 +78,9 @@ struct rt_ctx {
 
 namespace {
 
-std::string g_create_err;
+thread_local std::string g_create_err;   // rt_ctx_create has no context to hang its error text on
+
+constexpr size_t MAX_EVENT_PAIRS = 512;   // bound on live HIP events per context (see harvest_events)
 
 int fail(rt_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_err = msg;
@@ -96,6 +100,22 @@ int ensure(rt_ctx* ctx, DevBuf& b, size_t bytes) {
     size_t cap = bytes + bytes / 8 + 256;
     HIPCHK(ctx, hipMalloc(&b.p, cap));
     b.cap = cap;
+    return RT_OK;
+}
+
+// Folds the recorded launch durations into ctx->ms_harvested and frees the event pairs for reuse.  Waits for the last
+// recorded launch: called by the counter readers, and by the enqueue path once MAX_EVENT_PAIRS launches are outstanding
+// so that a caller who never reads the counters (a serving loop on rt_is_estimate_dev) holds a bounded number of events.
+int harvest_events(rt_ctx* ctx) {
+    if (ctx->events_used == 0) return RT_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->events[ctx->events_used - 1].second));
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        float t = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->events[i].first, ctx->events[i].second));
+        ctx->ms_harvested += t;
+    }
+    ctx->launches_harvested += ctx->events_used;
+    ctx->events_used = 0;
     return RT_OK;
 }
 
@@ -168,6 +188,29 @@ int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArg
     return RT_OK;
 }
 
+// How one launch over N query points x S samples is laid out as passes (see the comment above is_fused_kernel).
+struct IsPlan {
+    int64_t ppp, p_main, p_total, E;
+    int rem, q;
+};
+IsPlan is_plan(int64_t N, int64_t S, int nst) {
+    const int MS = 32 * nst;
+    const int64_t full = S / MS;
+    const int r = (int)(S - full * MS);
+    const bool packed = r > 0 && 2 * r <= MS;      // at least two query points fit into one leftover pass
+    IsPlan pl;
+    pl.ppp = packed ? full : (S + MS - 1) / MS;
+    pl.rem = packed ? r : 0;
+    pl.q = packed ? MS / r : 0;
+    pl.p_main = N * pl.ppp;
+    pl.p_total = pl.p_main + (packed ? (N + pl.q - 1) / pl.q : 0);
+    pl.E = pl.ppp + (packed ? 1 : 0);
+    return pl;
+}
+size_t is_partial_bytes(int64_t N, int64_t S, int nst, int n_sd) {
+    return (size_t)N * (size_t)is_plan(N, S, nst).E * n_sd * 2 * sizeof(double);
+}
+
 // Enqueues one launch of the fused kernel + finalize for N query points whose results go to out[k*out_stride + n].
 // All pointers are device pointers.
 int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
@@ -180,23 +223,16 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     int rc = make_sampler(ctx, scale, df, seed, a.sa);
     if (rc) return rc;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
-    // work units: (query point, chunk of samples); aim for >= 128 units per CU-resident workgroup
     const int nst = G.nst;
     const int MS = 32 * nst;
     const int grid_max = ctx->cu_count;
-    const int64_t passes = (S + MS - 1) / MS;
-    int64_t want = (128ll * grid_max + N - 1) / N;
-    if (want < 1) want = 1;
-    if (want > passes) want = passes;
-    const int64_t nchunks = want;
-    a.nchunks = (int)nchunks;
-    a.passes = passes;
-    a.n_units = N * nchunks;
+    const IsPlan pl = is_plan(N, S, nst);
+    a.ppp = pl.ppp; a.p_main = pl.p_main; a.p_total = pl.p_total; a.E = pl.E; a.rem = pl.rem; a.q = pl.q;
     a.N = N; a.S = S; a.y_index_base = y_index_base;
     a.y = y; a.xhat = xhat; a.xs = xs;
     a.n_sd = n_sd;
-    rc = ensure(ctx, ctx->b_partial, (size_t)a.n_units * n_sd * 2 * sizeof(double));
-    if (rc) return rc;
+    if (is_partial_bytes(N, S, nst, n_sd) > ctx->b_partial.cap)
+        return fail(ctx, RT_EINVAL, "internal: partial-result buffer smaller than the block needs");
     a.partial = (double*)ctx->b_partial.p;
     const double PI = 3.14159265358979323846;
     const double ct = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * PI) - log(scale);
@@ -210,7 +246,11 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     a.half_dfp1 = 0.5 * (df + 1.0);
 
     const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy);
-    const int grid = (int)((a.n_units < grid_max) ? a.n_units : grid_max);
+    const int grid = (int)((a.p_total < grid_max) ? a.p_total : grid_max);
+    if (ctx->events_used == MAX_EVENT_PAIRS) {
+        rc = harvest_events(ctx);
+        if (rc) return rc;
+    }
     if (ctx->events_used == ctx->events.size()) {
         hipEvent_t e0, e1;
         HIPCHK(ctx, hipEventCreate(&e0));
@@ -232,9 +272,8 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     ctx->events_used++;
     ctx->flops_acc += (double)N * (double)S * G.flops_per_row;
     ctx->evals_acc += (uint64_t)N * (uint64_t)S;
-    const int fb = 256;
-    hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + fb - 1) / fb)), dim3(fb), 0, ctx->stream,
-                       (const double*)a.partial, N, a.nchunks, n_sd, log((double)S), log_flag, out, out_stride);
+    hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const double*)a.partial, N, a.E, n_sd, log((double)S), log_flag, out, out_stride);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -255,9 +294,25 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     if (N == 0) return RT_OK;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     int64_t per = ctx->max_launch_evals / S;
+    {   // ... and to 1 GiB of per-pass partial results (16 B per pass and sd value; only matters for tiny S)
+        const int64_t per_mem = (int64_t)((1ull << 30) / is_partial_bytes(1, S, G.nst, n_sd));
+        if (per > per_mem) per = per_mem;
+    }
     if (per < 1) per = 1;
     const int64_t nblocks = (N + per - 1) / per;
     per = (N + nblocks - 1) / nblocks;           // balanced blocks
+    // the partial-result buffer is sized ONCE for the largest block, before anything is enqueued: growing it between
+    // two launches of one call would free memory the previous launch may still be writing
+    {
+        size_t need = 0;
+        for (int64_t n0 = 0; n0 < N; n0 += per) {
+            const int64_t nb = (N - n0 < per) ? N - n0 : per;
+            const size_t b = is_partial_bytes(nb, S, G.nst, n_sd);
+            if (b > need) need = b;
+        }
+        const int rc = ensure(ctx, ctx->b_partial, need);
+        if (rc) return rc;
+    }
     for (int64_t n0 = 0; n0 < N; n0 += per) {
         const int64_t nb = (N - n0 < per) ? N - n0 : per;
         const int rc = is_enqueue_block(ctx, y + n0 * dy, xhat + n0 * dx, xs ? xs + (size_t)n0 * S * dx : nullptr, nb,
@@ -577,15 +632,11 @@ int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
     if (!ctx || !out) return RT_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    double ms = 0.0;
-    for (size_t i = 0; i < ctx->events_used; ++i) {
-        float t = 0.0f;
-        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->events[i].first, ctx->events[i].second));
-        ms += t;
-    }
-    out->kernel_ms = ms;
+    const int rc = harvest_events(ctx);
+    if (rc) return rc;
+    out->kernel_ms = ctx->ms_harvested;
     out->flops = ctx->flops_acc;
-    out->launches = ctx->events_used;
+    out->launches = ctx->launches_harvested;
     out->sample_evals = ctx->evals_acc;
     return RT_OK;
 }
@@ -595,6 +646,8 @@ int rt_reset_counters(rt_ctx* ctx) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->events_used = 0;
+    ctx->ms_harvested = 0.0;
+    ctx->launches_harvested = 0;
     ctx->flops_acc = 0.0;
     ctx->evals_acc = 0;
     return RT_OK;

@@ -4,6 +4,18 @@
 
 // ----------------------------------------------------------------------------------------------
 // Fused IS kernel.
+//
+// Work is a linear list of PASSES (one pass = MS samples through all of G's layers):
+//   main passes      p in [0, N*ppp):  query point n = p / ppp, pass j = p % ppp, samples [j*MS, min(S, (j+1)*MS));
+//   leftover passes  p in [N*ppp, p_total)  (packed mode only: rem = S % MS with 0 < rem <= MS/2):  the last `rem`
+//                    samples of q = MS / rem consecutive query points share one pass — slot s carries sample
+//                    ppp*MS + s % rem of point g*q + s / rem — instead of one 3/4-empty pass per point.
+// Workgroup b runs main passes [p_main*b/G, p_main*(b+1)/G) and then leftover passes [L*b/G, L*(b+1)/G): every workgroup
+// gets the same number of passes of either kind (+-1).
+// Every pass reduces ITS samples of ONE query point to (max v, sum exp(v - max)) and stores the pair:
+//   partial[((n*E + e)*n_sd + k)*2 ..+1],  e = j for a main pass, e = ppp for the point's share of a leftover pass.
+// is_finalize_kernel merges a point's E pairs in a fixed order, so the result does not depend on how passes were dealt to
+// workgroups, on N, on the launch split or on the GPU count: it is a function of (weights, y, xhat, S, seed, global index).
 // ----------------------------------------------------------------------------------------------
 struct IsArgs {
     MlpArgs g;
@@ -11,11 +23,14 @@ struct IsArgs {
     const double* y;        // N x dy
     const float* xhat;      // N x dx
     const double* xs;       // given samples N x S x dx, or nullptr
-    double* partial;        // n_units x n_sd x 2 : (max, sum exp(v - max))
+    double* partial;        // N x E x n_sd x 2
     int64_t N, S, y_index_base;
-    int64_t n_units;
-    int nchunks;            // chunks per query point
-    int64_t passes;         // ceil(S / samples per pass)
+    int64_t ppp;            // main passes per query point
+    int64_t p_main;         // N * ppp
+    int64_t p_total;        // p_main + number of leftover passes
+    int64_t E;              // partial entries per query point: ppp + (rem ? 1 : 0)
+    int rem;                // packed mode: samples per point in a leftover pass (S % MS); 0 = no leftover passes
+    int q;                  // packed mode: query points per leftover pass (MS / rem)
     // score constants (fp64)
     int n_sd;               // number of sd_y values scored on the same draws and the same G pass (1..RT_MAX_SD)
     double c_all[RT_MAX_SD];     // -dy*log(sqrt(2pi)*sd) - dx*log(sqrt(2pi)) - dx*ct(df, scale)
@@ -26,7 +41,7 @@ struct IsArgs {
 };
 
 struct Carve {
-    int x0, act, scr, lse, yb, xh, total;
+    int x0, act, scr, yb, xh, total;
 };
 
 __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim) {
@@ -38,11 +53,47 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     if (part_bytes > act_bytes) act_bytes = part_bytes;
     c.act = off; off += act_bytes;
     c.scr = off; off += 2 * NTHREADS * 8;            // per (phase, sample): squared error, log weight
-    c.lse = off; off += 2 * RT_MAX_SD * ms * 8;      // per (sd, sample slot): running max, running sum
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
     c.total = off;
     return c;
+}
+
+// Wave-wide fp64 reductions on DPP moves (an inclusive scan: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3; lane 63 holds the total, read back to every lane).
+// About 20 VALU instructions — the ds_bpermute butterfly of __shfl_xor costs ~3000 cycles of dependent LDS latency,
+// which matters here because the fused kernel reduces once per pass.  Fixed evaluation order: deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v, double identity) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long id = (unsigned long long)__double_as_longlong(identity);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)id, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(id >> 32), (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double read_lane63(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_max(double v) {      // v must not be NaN
+    v = fmax(v, dpp_fetch<0x111, 0xF>(v, -INFINITY));
+    v = fmax(v, dpp_fetch<0x112, 0xF>(v, -INFINITY));
+    v = fmax(v, dpp_fetch<0x114, 0xF>(v, -INFINITY));
+    v = fmax(v, dpp_fetch<0x118, 0xF>(v, -INFINITY));
+    v = fmax(v, dpp_fetch<0x142, 0xA>(v, -INFINITY));
+    v = fmax(v, dpp_fetch<0x143, 0xC>(v, -INFINITY));
+    return read_lane63(v);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_fetch<0x111, 0xF>(v, 0.0);
+    v += dpp_fetch<0x112, 0xF>(v, 0.0);
+    v += dpp_fetch<0x114, 0xF>(v, 0.0);
+    v += dpp_fetch<0x118, 0xF>(v, 0.0);
+    v += dpp_fetch<0x142, 0xA>(v, 0.0);
+    v += dpp_fetch<0x143, 0xC>(v, 0.0);
+    return read_lane63(v);
 }
 
 // One workgroup per CU, up to 512 registers per wave.  NST = 2: 64 samples per pass (hidden width <= 512).
@@ -59,7 +110,6 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     double* scr = (double*)(smem + cv.scr);
-    double* lse = (double*)(smem + cv.lse);
     double* yb = (double*)(smem + cv.yb);
     float* xh = (float*)(smem + cv.xh);
     const float* part = (const float*)act;
@@ -77,100 +127,124 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
     st.t = __builtin_amdgcn_s_memtime();
 #endif
-    // contiguous block of work units per workgroup: every workgroup gets the same mix of chunk sizes
-    const int64_t u_lo = a.n_units * (int64_t)blockIdx.x / gridDim.x;
-    const int64_t u_hi = a.n_units * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    for (int64_t unit = u_lo; unit < u_hi; ++unit) {
-        const int64_t n = unit / a.nchunks;
-        const int c = (int)(unit - n * a.nchunks);
-        // chunk c = passes [c*P/nchunks, (c+1)*P/nchunks): sizes differ by at most one pass
-        const int64_t s_begin = (a.passes * c / a.nchunks) * MS;
-        const int64_t s_hi = (a.passes * (c + 1) / a.nchunks) * MS;
-        const int64_t s_end = (s_hi < a.S) ? s_hi : a.S;
-        __syncthreads();   // previous unit's readers of yb / xh are done
-        for (int d = tid; d < dy; d += NTHREADS) yb[d] = a.y[n * dy + d];
-        for (int d = tid; d < dx; d += NTHREADS) xh[d] = a.xhat[n * dx + d];
-        __syncthreads();
+    // this workgroup's share of the main passes and of the leftover passes (a leftover pass costs a few percent more
+    // than a main one — per-slot query points — so they are dealt evenly too, not left to the last workgroups)
+    const int64_t n_left = a.p_total - a.p_main;
+    const int64_t m_lo = a.p_main * (int64_t)blockIdx.x / gridDim.x, m_hi = a.p_main * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    const int64_t l_lo = n_left * (int64_t)blockIdx.x / gridDim.x, l_hi = n_left * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    const int64_t n_mine = (m_hi - m_lo) + (l_hi - l_lo);
+    // (query point, pass of that point) of the current main pass, advanced incrementally.  (Narrowing this loop state to
+    // 32 bits was tried: the register allocator then moves 21 more values between VGPRs and AGPRs inside the MLP, +0.9 %.)
+    int64_t n_u = 0, j_u = 0;
+    if (m_lo < m_hi) { n_u = m_lo / a.ppp; j_u = m_lo - n_u * a.ppp; }
+    int64_t n_loaded = -1;                  // query point whose y / xhat sit in LDS
+    auto put_x0 = [&](int d, float v) __attribute__((always_inline)) { *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v; };
 
-        // online log-sum-exp state per (sd, sample slot) lives in LDS: lse[(2k)*MS + s] = max, [(2k+1)*MS + s] = sum
-        if (tid < MS)
-            for (int k = 0; k < a.n_sd; ++k) { lse[(2 * k) * MS + s] = -INFINITY; lse[(2 * k + 1) * MS + s] = 0.0; }
-
-        for (int64_t sb = s_begin; sb < s_end; sb += MS) {
-            const int64_t si = sb + s;           // this thread's sample index
-            ST(7)
-            MlpPre<HID> pre;
-            mlp_prefetch<HID, NST>(m, pre, wave, lane);
-            // ---- A. proposal samples -> x0 image --------------------------------------------------
-            if (GIVEN) {
-                if (si < s_end) {
-                    const double* src = a.xs + ((size_t)n * a.S + si) * dx;
-                    for (int d = p; d < dx; d += NP)
-                        *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = (float)src[d];
-                } else {
-                    for (int d = p; d < dx; d += NP)
-                        *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = 0.0f;
-                }
-            } else if (tid < MS) {
-                draw_sample(a.sa, (uint64_t)(a.y_index_base + n), (uint32_t)si, xh, dx,
-                            [&](int d, float v) {
-                                *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v;
-                            });
+    for (int64_t ps = 0; ps < n_mine; ++ps) {
+        const bool left = ps >= m_hi - m_lo;            // uniform over the workgroup
+        const int64_t g_u = l_lo + (ps - (m_hi - m_lo));   // leftover pass index
+        // a slot's query point, sample index and whether it carries a sample at all.  Leftover passes: slot s_ carries
+        // sample ppp*MS + s_ % rem of the (s_ / rem)-th query point of the pass.  Computed from uniform state and the slot
+        // number alone, and computed AGAIN after the MLP (from a laundered copy of the slot number, so that the compiler
+        // cannot keep the first results alive): nothing per-thread but tid stays in registers across mlp_core.
+        struct Slot { int64_t n, si; bool valid; };
+        auto slot_of = [&](int s_) __attribute__((always_inline)) {
+            Slot r;
+            if (!left) { r.n = n_u; r.si = j_u * MS + s_; r.valid = r.si < a.S; }
+            else {
+                const int pt = s_ / a.rem, off = s_ - pt * a.rem;
+                r.n = g_u * a.q + pt; r.si = a.ppp * MS + off; r.valid = pt < a.q && r.n < a.N;
             }
+            return r;
+        };
+        if (!left && n_u != n_loaded) {
+            // the previous pass's readers of yb / xh are past the barrier that ends its scoring phase
+            for (int d = tid; d < dy; d += NTHREADS) yb[d] = a.y[n_u * dy + d];
+            for (int d = tid; d < dx; d += NTHREADS) xh[d] = a.xhat[n_u * dx + d];
+            n_loaded = n_u;
             __syncthreads();
-            ST(0)
-            // ---- B. G forward ---------------------------------------------------------------------
-            mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
-            // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
-            double se = 0.0;
+        }
+        ST(7)
+        MlpPre<HID> pre;
+        mlp_prefetch<HID, NST>(m, pre, wave, lane);
+        // ---- A. proposal samples -> x0 image --------------------------------------------------
+        {
+            const Slot sl = slot_of(s);
+            if (GIVEN) {
+                const double* src = a.xs + (sl.valid ? ((size_t)sl.n * a.S + sl.si) * dx : 0);
+                for (int d = p; d < dx; d += NP) put_x0(d, sl.valid ? (float)src[d] : 0.0f);
+            } else if (tid < MS) {
+                if (!sl.valid) { for (int d = 0; d < dx; ++d) put_x0(d, 0.0f); }
+                else if (!left) draw_sample(a.sa, (uint64_t)(a.y_index_base + sl.n), (uint32_t)sl.si, xh, dx, put_x0);
+                else draw_sample(a.sa, (uint64_t)(a.y_index_base + sl.n), (uint32_t)sl.si, a.xhat + sl.n * dx, dx, put_x0);
+            }
+        }
+        __syncthreads();
+        ST(0)
+        // ---- B. G forward ---------------------------------------------------------------------
+        mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
+        // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
+        int s2 = s;
+        asm volatile("" : "+v"(s2));
+        const Slot sl = slot_of(s2);
+        const bool valid = sl.valid;
+        const int64_t n_c = valid ? sl.n : 0;           // in-bounds row for the loads of slots that carry nothing
+        double se = 0.0, lw = 0.0;
+        auto score = [&](const auto* yrow, const auto* centre) __attribute__((always_inline)) {
             for (int d = p; d < dy; d += NP) {
-                const double diff = yb[d] - (double)mlp_out<MS>(m, part, d, s);
+                const double diff = (double)yrow[d] - (double)mlp_out<MS>(m, part, d, s);
                 se += diff * diff;
             }
-            double lw = 0.0;
             for (int d = p; d < dx; d += NP) {
                 double x;
-                if (GIVEN) x = (si < s_end) ? a.xs[((size_t)n * a.S + si) * dx + d] : 0.0;
+                if (GIVEN) x = valid ? a.xs[((size_t)n_c * a.S + sl.si) * dx + d] : 0.0;
                 else x = (double)*(const float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
-                const double u = ((double)xh[d] - x) * a.inv_scale;
+                const double u = ((double)centre[d] - x) * a.inv_scale;
                 lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
             }
-            scr[p * MS + s] = se;
-            scr[NTHREADS + p * MS + s] = lw;
-            __syncthreads();
-            // ---- D. online log-sum-exp (one thread per sample; one state per sd_y) ------------------
-            if (tid < MS && si < s_end) {
-                double se_t = scr[s], lw_t = scr[NTHREADS + s];
+        };
+        if (!left) score((const double*)yb, (const float*)xh);
+        else score(a.y + n_c * dy, a.xhat + n_c * dx);
+        scr[p * MS + s] = se;
+        scr[NTHREADS + p * MS + s] = lw;
+        __syncthreads();
+        // ---- D. this pass's log-sum-exp pairs (wave 0; lane = sample slot) ----------------------
+        if (wave == 0) {
+            double se_t = 0.0, lw_t = 0.0;
+            if (lane < MS) {
+                se_t = scr[lane]; lw_t = scr[NTHREADS + lane];
 #pragma unroll
-                for (int q = 1; q < NP; ++q) { se_t += scr[q * MS + s]; lw_t += scr[NTHREADS + q * MS + s]; }
-                for (int k = 0; k < a.n_sd; ++k) {
-                    const double v = a.c_all[k] + (lw_t - se_t * a.inv_2sd2[k]);
-                    if (v > -INFINITY && v < INFINITY) {
-                        double run_m = lse[(2 * k) * MS + s], run_s = lse[(2 * k + 1) * MS + s];
-                        if (v > run_m) { run_s = run_s * exp(run_m - v) + 1.0; run_m = v; }
-                        else run_s += exp(v - run_m);
-                        lse[(2 * k) * MS + s] = run_m;
-                        lse[(2 * k + 1) * MS + s] = run_s;
+                for (int qq = 1; qq < NP; ++qq) { se_t += scr[qq * MS + lane]; lw_t += scr[NTHREADS + qq * MS + lane]; }
+            }
+            const bool live = lane < MS && valid;
+            for (int k = 0; k < a.n_sd; ++k) {
+                double v = a.c_all[k] + (lw_t - se_t * a.inv_2sd2[k]);
+                if (!(live && v > -INFINITY && v < INFINITY)) v = -INFINITY;   // empty slot / non-finite score: weight 0
+                if (!left) {
+                    const double M = wave_max(v);
+                    const double t = wave_sum((v > -INFINITY) ? exp(v - M) : 0.0);
+                    if (lane == 0) {
+                        double* dst = a.partial + 2 * ((n_u * a.E + j_u) * a.n_sd + k);
+                        dst[0] = M; dst[1] = t;
+                    }
+                } else {
+                    // lane i < q owns the i-th query point of the pass: slots i*rem .. i*rem + rem - 1
+                    double M = -INFINITY;
+                    for (int o = 0; o < a.rem; ++o) M = fmax(M, __shfl(v, (lane * a.rem + o) & 63));
+                    double t = 0.0;
+                    for (int o = 0; o < a.rem; ++o) {
+                        const double w = __shfl(v, (lane * a.rem + o) & 63);
+                        t += (w > -INFINITY) ? exp(w - M) : 0.0;
+                    }
+                    const int64_t n_o = g_u * a.q + lane;
+                    if (lane < a.q && n_o < a.N) {
+                        double* dst = a.partial + 2 * ((n_o * a.E + a.ppp) * a.n_sd + k);
+                        dst[0] = M; dst[1] = t;
                     }
                 }
             }
         }
-        if (wave == 0) {
-            for (int k = 0; k < a.n_sd; ++k) {
-                const double run_m = (lane < MS) ? lse[(2 * k) * MS + lane] : -INFINITY;
-                const double run_s = (lane < MS) ? lse[(2 * k + 1) * MS + lane] : 0.0;
-                double M = run_m;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
-                double t = (run_m > -INFINITY) ? run_s * exp(run_m - M) : 0.0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-                if (lane == 0) {
-                    a.partial[2 * (unit * a.n_sd + k)] = M;
-                    a.partial[2 * (unit * a.n_sd + k) + 1] = t;
-                }
-            }
-        }
+        if (!left && ++j_u == a.ppp) { j_u = 0; ++n_u; }
     }
 #ifdef RT_STAMPS
 #if RT_STAMPS == 2
@@ -181,21 +255,25 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
 #endif
 }
 
-// out[k*out_stride + n] for sd index k: merges the chunks of query point n (n < N, this launch's block).
-__global__ void is_finalize_kernel(const double* partial, int64_t N, int nchunks, int n_sd, double logS,
-                                   int log_flag, double* out, int64_t out_stride) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// out[k*out_stride + n] for sd index k: merges the E pairs of query point n (n < N, this launch's block) in a fixed
+// order — one wave per point, lane l takes entries l, l+64, ..., then a butterfly over the lanes.
+__global__ __launch_bounds__(256) void is_finalize_kernel(const double* partial, int64_t N, int64_t E, int n_sd,
+                                                          double logS, int log_flag, double* out, int64_t out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;                     // the whole wave leaves together
+    const int64_t cs = 2 * n_sd;            // entry stride in doubles
     for (int k = 0; k < n_sd; ++k) {
-        const double* p = partial + 2 * (n * nchunks * n_sd + k);   // chunk stride: 2*n_sd doubles
-        const int cs = 2 * n_sd;
+        const double* p = partial + 2 * (n * E * n_sd + k);
         double M = -INFINITY;
-        for (int c = 0; c < nchunks; ++c) M = fmax(M, p[c * cs]);
+        for (int64_t e = lane; e < E; e += 64) M = fmax(M, p[e * cs]);
+        M = wave_max(M);
         double t = 0.0;
-        for (int c = 0; c < nchunks; ++c)
-            if (p[c * cs] > -INFINITY) t += p[c * cs + 1] * exp(p[c * cs] - M);
+        for (int64_t e = lane; e < E; e += 64)
+            if (p[e * cs] > -INFINITY) t += p[e * cs + 1] * exp(p[e * cs] - M);
+        t = wave_sum(t);
         const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
-        out[(int64_t)k * out_stride + n] = log_flag ? lp : exp(lp);
+        if (lane == 0) out[(int64_t)k * out_stride + n] = log_flag ? lp : exp(lp);
     }
 }
 

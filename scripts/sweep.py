@@ -6,8 +6,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from roundtrip_amd import _lib
-from oracle import is_ref   # weights only (Glorot initialiser); nothing is computed by the oracle here
+from roundtrip_amd import _lib, Generator
 
 PEAK = 157.3
 CONFIGS = [
@@ -34,10 +33,10 @@ def main():
     rows = []
     for name, dx, dy, hid, S, sd, scale, target in CONFIGS:
         rng = np.random.RandomState(1234)
-        gw, gb = is_ref.glorot_mlp([dx] + [hid] * 10 + [dy], rng)
-        hw, hb = is_ref.glorot_mlp([dy] + [256] * 10 + [dx], rng)
-        eng.set_mlp(_lib.RT_MLP_G, gw, gb)
-        eng.set_mlp(_lib.RT_MLP_H, hw, hb)
+        g = Generator(dx, dy, "g_net", nb_layers=10, nb_units=hid, rng=rng)
+        h = Generator(dy, dx, "h_net", nb_layers=10, nb_units=256, rng=rng)
+        eng.set_mlp(_lib.RT_MLP_G, g.weights, g.biases, g.alpha)
+        eng.set_mlp(_lib.RT_MLP_H, h.weights, h.biases, h.alpha)
         N = max(256, int(target // S))
         y = np.random.RandomState(42).standard_normal((N, dy))
         y_dev = torch.from_numpy(y).to(dev)

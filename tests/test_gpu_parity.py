@@ -206,23 +206,23 @@ def test_sampler_statistics(engine, make_nets):
 
 
 def test_sharding_and_chunking_invariance(engine, make_nets):
-    """Results depend on the GLOBAL query index only: evaluating a block with y_index_base = its offset is
-    bit-identical to evaluating everything at once (what makes any GPU count give the same answer), and the
-    sample-chunk decomposition (small N => many chunks per point) does not change the value beyond fp64
-    re-association."""
+    """Results are a function of (weights, y, xhat, S, seed, GLOBAL query index) only: every pass reduces its samples of
+    one query point to a (max, sum) pair and a point's pairs are merged in a fixed order, so neither the number of query
+    points in a call, nor a rank's offset, nor how passes were dealt to workgroups changes a single bit — what makes any
+    GPU count give the same answer.  S = 650 = 10 full passes + 10 samples: exercises the packed leftover passes too."""
     gw, gb, hw, hb = make_nets(2, 2)
     engine.set_mlp(G, gw, gb)
     engine.set_mlp(H, hw, hb)
-    y = np.random.RandomState(5).standard_normal((600, 2)) * 0.2
+    y = np.random.RandomState(5).standard_normal((601, 2)) * 0.2
     xhat = engine.mlp_forward(H, y.astype(np.float32))
-    S = 640
-    full = engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0)
-    assert np.array_equal(full, engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0))     # deterministic
-    parts = [engine.is_estimate(y[lo:hi], xhat[lo:hi], S, 0.05, 0.5, 1.0, seed=0, y_index_base=lo)
-             for lo, hi in ((0, 300), (300, 600))]
-    np.testing.assert_allclose(np.concatenate(parts), full, rtol=1e-13)
-    one = engine.is_estimate(y[7:8], xhat[7:8], S, 0.05, 0.5, 1.0, seed=0, y_index_base=7)   # 1 point: 10 chunks
-    np.testing.assert_allclose(one, full[7:8], rtol=1e-13)
+    for S in (640, 650, 37):
+        full = engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0)
+        assert np.array_equal(full, engine.is_estimate(y, xhat, S, 0.05, 0.5, 1.0, seed=0))     # deterministic
+        parts = [engine.is_estimate(y[lo:hi], xhat[lo:hi], S, 0.05, 0.5, 1.0, seed=0, y_index_base=lo)
+                 for lo, hi in ((0, 300), (300, 305), (305, 601))]
+        assert np.array_equal(np.concatenate(parts), full)
+        one = engine.is_estimate(y[7:8], xhat[7:8], S, 0.05, 0.5, 1.0, seed=0, y_index_base=7)   # one point alone
+        assert np.array_equal(one, full[7:8])
 
 
 def test_large_calls_split_into_bounded_launches(engine, make_nets, monkeypatch):
@@ -244,29 +244,76 @@ def test_large_calls_split_into_bounded_launches(engine, make_nets, monkeypatch)
         many = small.is_estimate(y, xhat, S, 0.3, 0.1, 1.0, seed=3, y_index_base=11)
         assert engine.counters()["launches"] == 1 and small.counters()["launches"] == 8
         assert small.counters()["sample_evals"] == 37 * S
-        np.testing.assert_allclose(many, one, rtol=1e-13)
+        assert np.array_equal(many, one)                       # bit for bit: the split changes no draw and no merge order
         sds = [0.05, 0.3, 1.0]
-        np.testing.assert_allclose(small.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3),
-                                   engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3), rtol=1e-13)
+        assert np.array_equal(small.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3),
+                              engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3))
         xs = engine.draw_samples(xhat, S, 0.1, 1.0, seed=3).astype(np.float64)
-        np.testing.assert_allclose(small.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False),
-                                   engine.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False), rtol=1e-13)
+        assert np.array_equal(small.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False),
+                              engine.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False))
     finally:
         small.close()
 
 
-@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 129])
+def test_event_pool_is_bounded_over_many_launches(engine, make_nets, monkeypatch):
+    """The per-launch HIP events that feed rt_get_counters are harvested every 512 launches, so a caller that never
+    reads the counters holds a bounded number of them; the counters still cover every launch."""
+    gw, gb, hw, hb = make_nets(2, 2)
+    y = np.random.RandomState(16).standard_normal((1100, 2)) * 0.2
+    S = 64
+    monkeypatch.setenv("RT_IS_MAX_LAUNCH_EVALS", str(S))                     # one query point per launch
+    small = _lib.Engine(0)
+    try:
+        for e in (engine, small):
+            e.set_mlp(G, gw, gb)
+            e.set_mlp(H, hw, hb)
+        xhat = engine.mlp_forward(H, y.astype(np.float32))
+        small.reset_counters()
+        many = small.is_estimate(y, xhat, S, 0.1, 0.5, 1.0, seed=2)
+        c = small.counters()
+        assert c["launches"] == 1100 and c["sample_evals"] == 1100 * S and c["kernel_ms"] > 0
+        assert np.array_equal(many, engine.is_estimate(y, xhat, S, 0.1, 0.5, 1.0, seed=2))
+    finally:
+        small.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 16, 17, 31, 32, 33, 63, 64, 65, 80, 96, 129])
 def test_ragged_sample_counts(engine, make_nets, S):
+    """S % 64 in (0, 32]: the last samples of 64 // (S % 64) query points share one leftover pass; above 32 a point's
+    last pass is simply part full.  7 query points, so the last leftover pass is itself ragged.  Plain, several-sd and
+    given-samples calls against the oracle on the same draws."""
     gw, gb, hw, hb = make_nets(3, 6)
     engine.set_mlp(G, gw, gb)
     engine.set_mlp(H, hw, hb)
     og = c_oracle.OracleMlp(gw, gb)
-    y = np.random.RandomState(8).standard_normal((3, 6)) * 0.1
+    y = np.random.RandomState(8).standard_normal((7, 6)) * 0.1
     xhat = engine.mlp_forward(H, y.astype(np.float32))
     got = engine.is_estimate(y, xhat, S, 0.5, 0.1, 1.0, seed=1)
     xs = engine.draw_samples(xhat, S, 0.1, 1.0, seed=1).astype(np.float64)
     want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.1, 1.0, True, c_oracle.ORDER_KERNEL)
-    np.testing.assert_allclose(got, want, rtol=1e-12)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)   # atol: log p(y) itself can be ~1e-3 (M + log t - log S cancels)
+    np.testing.assert_allclose(engine.is_estimate_given_samples(y, xhat, xs, 0.5, 0.1, 1.0), want, rtol=1e-12, atol=1e-14)   # atol: log p(y) itself can be ~1e-3 (M + log t - log S cancels)
+    multi = engine.is_estimate_multi(y, xhat, S, [0.5, 0.2], 0.1, 1.0, seed=1)
+    assert np.array_equal(multi[0], got)
+    want2 = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.2, 0.1, 1.0, True, c_oracle.ORDER_KERNEL)
+    np.testing.assert_allclose(multi[1], want2, rtol=1e-12, atol=1e-14)   # atol: log p(y) itself can be ~1e-3 (M + log t - log S cancels)
+
+
+@pytest.mark.parametrize("S", [1, 8, 16, 17, 40, 100])
+def test_ragged_sample_counts_on_32_sample_passes(engine, S):
+    """Hidden width 1024 runs 32-sample passes: leftovers are packed for S % 32 in (0, 16]."""
+    rng = np.random.RandomState(31)
+    gw, gb = is_ref.glorot_mlp([3, 1024, 1024, 4], rng)
+    for b in gb:
+        b += rng.standard_normal(b.shape).astype(np.float32) * 0.05
+    engine.set_mlp(G, gw, gb)
+    og = c_oracle.OracleMlp(gw, gb)
+    y = rng.standard_normal((5, 4)) * 0.1
+    xhat = (rng.standard_normal((5, 3)) * 0.1).astype(np.float32)
+    got = engine.is_estimate(y, xhat, S, 0.5, 0.2, 1.0, seed=4)
+    xs = engine.draw_samples(xhat, S, 0.2, 1.0, seed=4).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.2, 1.0, True, c_oracle.ORDER_KERNEL)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)   # atol: log p(y) itself can be ~1e-3 (M + log t - log S cancels)
 
 
 def test_empty_and_error_paths(engine, make_nets):
