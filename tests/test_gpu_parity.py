@@ -474,3 +474,54 @@ def test_jacobian_golden(engine, name):
     out, J = engine.mlp_jacobian(G, f["xhat"])
     np.testing.assert_allclose(out, f["g_of_xhat"], rtol=2e-5, atol=1e-7)
     assert np.abs(J - f["jac_at_xhat"]).max() <= 1e-5 * np.abs(f["jac_at_xhat"]).max()
+
+
+def _random_case(rng):
+    n_hidden = int(rng.randint(1, 5))
+    top = int(rng.choice([128, 256, 512, 512, 1024]))
+    widths = [int(rng.randint(max(1, top // 2 - 30), top + 1)) for _ in range(n_hidden)]
+    widths[int(rng.randint(n_hidden))] = int(rng.randint(top // 2 + 1, top + 1))      # pins the kernel width class
+    dx, dy = int(rng.randint(1, 25)), int(rng.randint(1, 101))
+    return dict(dims=[dx] + widths + [dy], N=int(rng.randint(1, 10)), S=int(rng.randint(1, 300)),
+                df=float(rng.choice([1.0, 2.0, 3.0, 2.5, 7.3])), sd=float(rng.choice([0.05, 0.3, 1.0])),
+                scale=float(rng.choice([0.01, 0.1, 0.5, 1.0])), alpha=float(rng.choice([0.2, 0.2, 0.0, 1.0, 0.37])),
+                base=int(rng.choice([0, 11, 2 ** 32 - 3, 2 ** 40 + 5])), seed=int(rng.randint(0, 2 ** 31)),
+                log=bool(rng.randint(2)))
+
+
+@pytest.mark.parametrize("case_seed", range(64))
+def test_random_shapes_against_the_oracle(engine, case_seed):
+    """Seeded random network shapes (1-4 hidden layers of unequal widths up to 1024, dx up to 24, dy up to 100, any
+    leaky-ReLU slope), sample counts, df, scale, sd, seeds and global index bases (beyond 2^32): forward bit-exact, the
+    estimate on the GPU's own draws equal to the oracle's scoring of those draws, several sd values in one pass, and
+    the result independent of the call the point sits in."""
+    rng = np.random.RandomState(1000 + case_seed)
+    c = _random_case(rng)
+    dims, N, S = c["dims"], c["N"], c["S"]
+    gw, gb = is_ref.glorot_mlp(dims, rng)
+    gb = [(rng.standard_normal(b.shape) * 0.05).astype(np.float32) for b in gb]
+    engine.set_mlp(G, gw, gb, alpha=c["alpha"])
+    og = c_oracle.OracleMlp(gw, gb, c["alpha"])
+    x = (rng.standard_normal((70, dims[0])) * 2).astype(np.float32)
+    assert np.array_equal(engine.mlp_forward(G, x), og.forward(x, order=c_oracle.ORDER_KERNEL)), c
+    y = rng.standard_normal((N, dims[-1])) * 0.3
+    xhat = (rng.standard_normal((N, dims[0])) * 0.3).astype(np.float32)
+    kw = dict(df=c["df"], seed=c["seed"], y_index_base=c["base"])
+    got = engine.is_estimate(y, xhat, S, c["sd"], c["scale"], log=c["log"], **kw)
+    xs = engine.draw_samples(xhat, S, c["scale"], **kw).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, c["sd"], c["scale"], c["df"], c["log"], c_oracle.ORDER_KERNEL)
+    if c["log"]:
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13, err_msg=str(c))
+    else:
+        # log=False: the reference (and the oracle, which follows it) multiplies p(y|x_i) and w_i in linear space, where
+        # terms below ~1e-308 flush to zero one by one; the GPU reduces in log space and exponentiates once, so down in
+        # the underflow zone it can return a denormal-scale value where the reference says exactly 0 (SURVEY.md §7)
+        ok = want > 1e-280
+        assert np.all(got[~ok] < 1e-270), c
+        np.testing.assert_allclose(np.log(got[ok]), np.log(want[ok]), rtol=1e-11, atol=1e-9, err_msg=str(c))
+    multi = engine.is_estimate_multi(y, xhat, S, [c["sd"], 2 * c["sd"]], c["scale"], log=c["log"], **kw)
+    assert np.array_equal(multi[0], got), c
+    k = N // 2
+    alone = engine.is_estimate(y[k:k + 1], xhat[k:k + 1], S, c["sd"], c["scale"], log=c["log"], df=c["df"],
+                               seed=c["seed"], y_index_base=c["base"] + k)
+    assert np.array_equal(alone, got[k:k + 1]), c
