@@ -504,6 +504,10 @@ def test_random_shapes_against_the_oracle(engine, case_seed):
     og = c_oracle.OracleMlp(gw, gb, c["alpha"])
     x = (rng.standard_normal((70, dims[0])) * 2).astype(np.float32)
     assert np.array_equal(engine.mlp_forward(G, x), og.forward(x, order=c_oracle.ORDER_KERNEL)), c
+    if max(dims[1:-1]) <= 512:                                   # the Jacobian kernel runs 64-column passes only
+        out, J = engine.mlp_jacobian(G, x[:37])
+        wout, wJ = og.jacobian(x[:37], c_oracle.ORDER_KERNEL)
+        assert np.array_equal(out, wout) and np.array_equal(J, wJ), c
     y = rng.standard_normal((N, dims[-1])) * 0.3
     xhat = (rng.standard_normal((N, dims[0])) * 0.3).astype(np.float32)
     kw = dict(df=c["df"], seed=c["seed"], y_index_base=c["base"])
