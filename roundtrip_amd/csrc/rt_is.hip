@@ -144,19 +144,23 @@ void free_mlp(HostMlp& m) {
     m.set = false;
 }
 
-template <int HID, int NST>
-int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
-    if (given) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((is_fused_kernel<HID, NST, true>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
-    } else {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((is_fused_kernel<HID, NST, false>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
-    }
+template <int HID, int NST, bool GIVEN, bool SHARE>
+int launch_is_variant(rt_ctx* ctx, const IsArgs& a, int grid, int lds) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, GIVEN, SHARE>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((is_fused_kernel<HID, NST, GIVEN, SHARE>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
+}
+
+template <int HID, int NST>
+int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
+    if (given) return launch_is_variant<HID, NST, true, false>(ctx, a, grid, lds);
+    // more than one Philox call per sample (4 normals each: df of them for chi2, then the dx coordinates; the gamma path
+    // of a non-integer df draws its chi2 apart): the threads of a sample slot share the calls
+    const bool share = a.sa.ndf + a.g.in_dim > 4;
+    return share ? launch_is_variant<HID, NST, false, true>(ctx, a, grid, lds)
+                 : launch_is_variant<HID, NST, false, false>(ctx, a, grid, lds);
 }
 
 template <int HID, int NST>

@@ -99,7 +99,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // One workgroup per CU, up to 512 registers per wave.  NST = 2: 64 samples per pass (hidden width <= 512).
 // NST = 1: 32 samples per pass, used for hidden width 1024, whose 64-sample activation image (256 KB)
 // would not fit in LDS.
-template <int HID, int NST, bool GIVEN>
+// SHARE: the NP threads of a sample slot share the sample's Philox calls (chosen by the host when a sample takes more
+// than one call, dx + df > 4); otherwise one thread draws the whole sample.  Same values either way (see draw_sample); a
+// separate instantiation because the register allocation of the one-call kernel — the 2-D sets, the bench — is kept as is.
+template <int HID, int NST, bool GIVEN, bool SHARE = false>
 __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     constexpr int MS = 32 * NST;          // samples per pass
     constexpr int NP = NTHREADS / MS;     // threads per sample in the scoring phase
@@ -173,6 +176,10 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             if (GIVEN) {
                 const double* src = a.xs + (sl.valid ? ((size_t)sl.n * a.S + sl.si) * dx : 0);
                 for (int d = p; d < dx; d += NP) put_x0(d, sl.valid ? (float)src[d] : 0.0f);
+            } else if (SHARE) {
+                if (!sl.valid) { for (int d = p; d < dx; d += NP) put_x0(d, 0.0f); }
+                else if (!left) draw_sample(a.sa, (uint64_t)(a.y_index_base + sl.n), (uint32_t)sl.si, xh, dx, put_x0, p, NP);
+                else draw_sample(a.sa, (uint64_t)(a.y_index_base + sl.n), (uint32_t)sl.si, a.xhat + sl.n * dx, dx, put_x0, p, NP);
             } else if (tid < MS) {
                 if (!sl.valid) { for (int d = 0; d < dx; ++d) put_x0(d, 0.0f); }
                 else if (!left) draw_sample(a.sa, (uint64_t)(a.y_index_base + sl.n), (uint32_t)sl.si, xh, dx, put_x0);

@@ -67,15 +67,21 @@ __device__ float chi2_over_df_gamma(const SamplerArgs& sa, uint32_t i, uint32_t 
     return 2.0f * g * boost / sa.df;
 }
 
-// Calls put(d, x_d) for d = 0 .. dx-1 with the proposal sample (yidx, i) around xhat.
+// Calls put(d, x_d) with the proposal sample (yidx, i) around xhat, for the coordinates d this thread owns.
+// Philox call c yields normals 4c .. 4c+3; the first ndf of them make chi2 (every thread needs that for `mult`), the
+// rest are coordinates.  The calls of one sample are independent, so `nphase` threads can share a sample: thread `phase`
+// evaluates the chi2 calls plus the coordinate calls c with c % nphase == phase and puts only the latter's coordinates.
+// phase = 0, nphase = 1: the whole sample.  The values do not depend on how the calls are shared.
 template <typename Put>
 __device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx, uint32_t i,
-                                            const float* xhat, int dx, Put put) {
+                                            const float* xhat, int dx, Put put, int phase = 0, int nphase = 1) {
     const uint32_t ylo = (uint32_t)yidx, yhi = (uint32_t)(yidx >> 32);
     float zsum = 0.0f, mult = 0.0f;
     if (sa.ndf == 0) mult = sa.scale / sqrtf(chi2_over_df_gamma(sa, i, ylo, yhi));
     const int total = sa.ndf + dx;
     for (int c = 0; 4 * c < total; ++c) {
+        const bool mine = c % nphase == phase;
+        if (!mine && 4 * c >= sa.ndf) continue;          // neither a chi2 call nor one of this thread's
         const U4 r = philox4x32_10(i, (uint32_t)c, ylo, yhi, sa.seed_lo, sa.seed_hi);
         float n[4];
         box_muller(r.x, r.y, n[0], n[1]);
@@ -86,11 +92,10 @@ __device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx
             if (g < sa.ndf) {
                 zsum += n[k] * n[k];
                 if (g == sa.ndf - 1) mult = sa.scale / sqrtf(zsum / sa.df);
-            } else if (g < total) {
+            } else if (g < total && mine) {
                 const int d = g - sa.ndf;
                 put(d, xhat[d] + mult * n[k]);
             }
         }
     }
 }
-

@@ -31,7 +31,10 @@ def main():
     dev = torch.device("cuda", 0)
     eng = _lib.Engine(0)
     rows = []
+    only = sys.argv[1] if len(sys.argv) > 1 else ""        # optional substring filter on the config name
     for name, dx, dy, hid, S, sd, scale, target in CONFIGS:
+        if only not in name:
+            continue
         rng = np.random.RandomState(1234)
         g = Generator(dx, dy, "g_net", nb_layers=10, nb_units=hid, rng=rng)
         h = Generator(dy, dx, "h_net", nb_layers=10, nb_units=256, rng=rng)
