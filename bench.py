@@ -66,11 +66,9 @@ def cpu_baseline(g, h, y, S, sd, scale, n_points, eng):
             "seconds": dt}
 
 
-def measured_traffic(grid, S, dx, dy):
-    """HBM-side bytes per launch of the fused kernel for THIS workload, from the committed PMC passes
-    (profiles/r*_pmc_v*.json, written by scripts/pmc.sh + scripts/pmc_profile.py: FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 --pmc runs, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read from
-    inside an unprofiled run, so the figure is the recorded one; None if no recorded pass matches the workload."""
+def recorded_traffic(grid, S, dx, dy):
+    """HBM-side bytes per launch of the fused kernel for THIS workload from the committed PMC passes
+    (profiles/r*_pmc_v*.json, written by scripts/pmc.sh + scripts/pmc_profile.py).  The fallback of live_traffic()."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_v*.json"))):
@@ -81,8 +79,61 @@ def measured_traffic(grid, S, dx, dy):
         k = d.get("bench_key", {})
         if (k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy")) == (grid, S, dx, dy) \
                 and "traffic_bytes_per_launch" in d:
-            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
+            best = (d["traffic_bytes_per_launch"], "PMC passes recorded in profiles/%s" % os.path.basename(f))
     return best
+
+
+def _pmc_pass(counter, grid, S, timeout_s=150):
+    """One rocprofv3 --pmc pass over a child run of this script (one launch of the same workload); returns the counter's
+    value for the last dispatch of the fused kernel, summed over its rows, or None."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+           "--grid", str(grid), "--sample-size", str(S), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--no-live-traffic"]
+    try:
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            if proc.wait(timeout=timeout_s) != 0:
+                return None
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)      # the exact process group started above
+            proc.wait()
+            return None
+        acc = {}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if "is_fused_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        d = int(row["Dispatch_Id"])
+                        acc[d] = acc.get(d, 0.0) + float(row["Counter_Value"])
+        return acc[max(acc)] if acc else None
+    except (OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic(grid, S):
+    """HBM-side bytes of ONE launch of the fused kernel on this workload, measured now: FETCH_SIZE and WRITE_SIZE from two
+    separate rocprofv3 --pmc passes over child runs of this script, corrected as MI355X_MICROARCH.md (HBM section)
+    prescribes: both are in KiB, and on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B/lane loads — the weight
+    stream — at 64 B, so it is doubled.  None when rocprofv3 is missing, a pass fails, or this process is itself being
+    profiled (a profiler inside a profiled run)."""
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    fetch = _pmc_pass("FETCH_SIZE", grid, S)
+    if fetch is None:
+        return None
+    write = _pmc_pass("WRITE_SIZE", grid, S)
+    if write is None:
+        return None
+    return (2.0 * fetch * 1024.0 + write * 1024.0, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate child "
+            "runs of one launch each), KiB units, FETCH doubled (gfx950 wide loads)")
 
 
 def main():
@@ -93,6 +144,8 @@ def main():
     ap.add_argument("--sample-size", type=int, default=10000)
     ap.add_argument("--grid", type=int, default=100, help="grid side; query points per GPU = grid^2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the PMC passes recorded under profiles/ instead of two live rocprofv3 passes")
     ap.add_argument("--cpu-points", type=int, default=160,
                     help="query points of the cpu_baseline sample (160 x S=10000 is about 13 s on 16 host cores)")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never used by the driver):
@@ -176,7 +229,11 @@ def main():
         evals = float(n_total) * S * args.steps
         res = (gathered if world > 1 else out_dev).cpu().numpy()
         achieved = ctr["flops"] / (ctr["kernel_ms"] * 1e-3) / 1e12 if ctr["kernel_ms"] > 0 else 0.0
-        traffic = measured_traffic(args.grid, S, dx, dy)
+        traffic = None
+        if world == 1 and not args.no_live_traffic:
+            traffic = live_traffic(args.grid, S)
+        if traffic is None:
+            traffic = recorded_traffic(args.grid, S, dx, dy)
         line = {
             "metric": "IS sample-evals/sec (N_y x S through G)",
             "value": evals / elapsed,
@@ -197,7 +254,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic[0] if traffic else None, "traffic_unit": "bytes/launch",
-                         "traffic_source": ("PMC passes recorded in profiles/%s" % traffic[1]) if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "kernel": "is_fused_kernel<512, 2, false, false>",
                          "kernel_ms_avg": ctr["kernel_ms"] / max(1, ctr["launches"]),
                          "launches": ctr["launches"],
