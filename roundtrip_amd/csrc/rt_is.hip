@@ -10,10 +10,11 @@
 //   * activations live in LDS (HID x 64 fp32) in a [k/8][sample][8] image that is both the B-operand
 //     read format (ds_read_b128 = four k-steps) and the accumulator write format (ds_write_b128);
 //   * weights are pre-packed on the host into per-lane A-operand order, so every wave streams ITS OWN
-//     feature slice straight global(L2) -> VGPR with 16-byte coalesced loads, software-pipelined one
-//     k-group ahead; no LDS staging and no barrier inside a layer's K loop;
-//   * the proposal sampler (Philox4x32-10 + Box-Muller), the Gaussian / Student-t scoring (fp64) and the
-//     online log-sum-exp are fused around the MLP, so nothing per-sample ever reaches HBM.
+//     feature slice straight global(L2) -> VGPR with 16-byte coalesced buffer loads, software-pipelined three
+//     k-groups ahead; no LDS staging of weights;
+//   * the proposal sampler (Philox4x32-10 + Box-Muller), the Gaussian / Student-t scoring (fp64) and a per-pass
+//     log-sum-exp pair are fused around the MLP, so nothing per-sample ever reaches HBM; the pairs of a query point
+//     are merged in a fixed order by a small second kernel, which makes results independent of the work partition.
 //
 // Nothing here falls back to the CPU: every entry point launches these kernels or returns an error.
 
