@@ -140,6 +140,27 @@ int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, 
                        int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
                        uint64_t seed, int log_flag, double* out_dev);
 
+/* --- Splitting one query point's SAMPLES over callers (second axis: fewer query points than GPUs) ------
+ * The fused kernel reduces every pass (64 samples; 32 at hidden width 1024) of a query point to a pair
+ * (max v, sum exp(v - max)); in packed mode the last S mod 64 samples of a point form one more pair.  rt_is_estimate
+ * merges a point's E pairs in a fixed order.  These three calls expose that: ranks compute disjoint ranges of the E
+ * pairs, exchange them (16 bytes per pair and sd value), and merge — the result is bit-identical to rt_is_estimate's.
+ * No counterpart in the reference (its loop over samples, main_density_est.py:331-335, is not distributed). */
+
+/* E = number of pairs per query point and sd value for sample_size S under the G that is set. */
+int rt_is_pair_count(rt_ctx* ctx, int64_t S, int64_t* E);
+
+/* Pairs [e_lo, e_hi) of every query point: pairs is N x (e_hi - e_lo) x n_sd x 2 float64 (max, sum).  Arguments as
+ * rt_is_estimate_multi. */
+int rt_is_pairs(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,
+                int n_sd, const double* sd_y, double scale, double df, uint64_t seed, int64_t e_lo, int64_t e_hi,
+                double* pairs);
+
+/* out (n_sd x N) = the estimates from all E pairs of every point: pairs is N x E x n_sd x 2, S the sample_size they
+ * were computed for (the reduction of main_density_est.py:339-345: log(sum exp v) - log S, or its exp). */
+int rt_is_merge_pairs(rt_ctx* ctx, const double* pairs, int64_t N, int64_t E, int n_sd, int64_t S, int log_flag,
+                      double* out);
+
 /* Device-resident rt_mlp_forward (in_dev/out_dev are device pointers); asynchronous like the above. */
 int rt_mlp_forward_dev(rt_ctx* ctx, int which, const float* in_dev, int64_t N, float* out_dev);
 

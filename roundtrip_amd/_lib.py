@@ -19,6 +19,7 @@ SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_mlp_jacobian", "rt_encode",
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
+    "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs",
 )
 
 
@@ -64,6 +65,9 @@ def load():
     lib.rt_get_counters.argtypes = [vp, C.POINTER(RtCounters)]
     lib.rt_reset_counters.argtypes = [vp]
     lib.rt_device_cu_count.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.rt_is_pair_count.argtypes = [vp, i64, C.POINTER(i64)]
+    lib.rt_is_pairs.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, dbl, dbl, C.c_uint64, i64, i64, vp]
+    lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name != "rt_last_error":
@@ -176,6 +180,43 @@ class Engine(object):
         self._chk(self._lib.rt_is_estimate_multi(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
                                                  int(sample_size), int(sds.size), sds.ctypes.data, float(scale),
                                                  float(df), int(seed), int(bool(log)), out.ctypes.data))
+        return out
+
+    # ---- one query point's samples split over callers (rt_is.h: pairs) --------------------------------------
+    def is_pair_count(self, sample_size):
+        """E: (max, sum) pairs per query point and sd value for this sample_size under the G that is set."""
+        e = C.c_int64(0)
+        self._chk(self._lib.rt_is_pair_count(self._h, C.c_int64(int(sample_size)), C.byref(e)))
+        return int(e.value)
+
+    def is_pairs(self, y, xhat, sample_size, sd_ys, scale, e_lo, e_hi, df=1.0, seed=0, y_index_base=0):
+        """Pairs [e_lo, e_hi) of every query point: (N, e_hi - e_lo, len(sd_ys), 2) float64."""
+        dx, dy = self._g_dims()
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != dy:
+            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
+        N = y.shape[0]
+        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
+        if xhat.shape != (N, dx):
+            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
+        out = np.empty((N, max(0, int(e_hi) - int(e_lo)), sds.size, 2), dtype=np.float64)
+        self._chk(self._lib.rt_is_pairs(self._h, y.ctypes.data, xhat.ctypes.data, C.c_int64(N),
+                                        C.c_int64(int(y_index_base)), C.c_int64(int(sample_size)), int(sds.size),
+                                        sds.ctypes.data, C.c_double(float(scale)), C.c_double(float(df)),
+                                        C.c_uint64(int(seed)), C.c_int64(int(e_lo)), C.c_int64(int(e_hi)),
+                                        out.ctypes.data))
+        return out
+
+    def is_merge_pairs(self, pairs, sample_size, log=True):
+        """(n_sd, N) estimates from all E pairs of every point: pairs is (N, E, n_sd, 2)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.float64)
+        if pairs.ndim != 4 or pairs.shape[3] != 2 or pairs.shape[1] < 1:
+            raise ValueError("expected pairs of shape (N, E, n_sd, 2), got %r" % (pairs.shape,))
+        N, E, n_sd, _ = pairs.shape
+        out = np.empty((n_sd, N), dtype=np.float64)
+        self._chk(self._lib.rt_is_merge_pairs(self._h, pairs.ctypes.data, C.c_int64(N), C.c_int64(E), int(n_sd),
+                                              C.c_int64(int(sample_size)), int(bool(log)), out.ctypes.data))
         return out
 
     def is_estimate_given_samples(self, y, xhat, x_samples, sd_y, scale, df=1.0, log=True):

@@ -216,11 +216,14 @@ size_t is_partial_bytes(int64_t N, int64_t S, int nst, int n_sd) {
     return (size_t)N * (size_t)is_plan(N, S, nst).E * n_sd * 2 * sizeof(double);
 }
 
-// Enqueues one launch of the fused kernel + finalize for N query points whose results go to out[k*out_stride + n].
+// Enqueues one launch of the fused kernel for N query points, computing the pairs [e_lo, e_hi) of every point into
+// ctx->b_partial (laid out N x E x n_sd x 2 whatever the range; e_hi < 0 means all E), and — when out is not NULL — the
+// finalize kernel whose results go to out[k*out_stride + n] (only meaningful for the full range).
 // All pointers are device pointers.
 int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
                      int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
-                     uint64_t seed, int log_flag, double* out, int64_t out_stride) {
+                     uint64_t seed, int log_flag, double* out, int64_t out_stride,
+                     int64_t e_lo = 0, int64_t e_hi = -1) {
     HostMlp& G = ctx->mlp[RT_MLP_G];
     IsArgs a;
     memset(&a, 0, sizeof(a));
@@ -232,7 +235,15 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     const int MS = 32 * nst;
     const int grid_max = ctx->cu_count;
     const IsPlan pl = is_plan(N, S, nst);
-    a.ppp = pl.ppp; a.p_main = pl.p_main; a.p_total = pl.p_total; a.E = pl.E; a.rem = pl.rem; a.q = pl.q;
+    if (e_hi < 0) e_hi = pl.E;
+    // main entries of the range, and whether the leftover entry (the last one, E - 1, in packed mode) is in it
+    const int64_t m_hi = e_hi < pl.ppp ? e_hi : pl.ppp;
+    const int64_t cnt = m_hi > e_lo ? m_hi - e_lo : 0;
+    const bool do_left = pl.rem > 0 && e_lo < pl.E && e_hi == pl.E;
+    a.ppp = cnt; a.j_lo = cnt ? e_lo : 0; a.left_s0 = pl.ppp * MS;
+    a.p_main = N * cnt; a.p_total = a.p_main + (do_left ? pl.p_total - pl.p_main : 0);
+    a.E = pl.E; a.rem = do_left ? pl.rem : 0; a.q = do_left ? pl.q : 0;
+    if (a.p_total == 0) return RT_OK;           // an empty range: nothing to run
     a.N = N; a.S = S; a.y_index_base = y_index_base;
     a.y = y; a.xhat = xhat; a.xs = xs;
     a.n_sd = n_sd;
@@ -275,8 +286,13 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
     ctx->events_used++;
-    ctx->flops_acc += (double)N * (double)S * G.flops_per_row;
-    ctx->evals_acc += (uint64_t)N * (uint64_t)S;
+    {   // sample-evals of this launch (the whole of S unless the call covers a range of a point's passes)
+        int64_t per_point = cnt * MS + (do_left ? pl.rem : 0);
+        if (pl.rem == 0 && cnt && e_lo + cnt == pl.ppp) per_point -= pl.ppp * MS - S;   // the part-full last main pass
+        ctx->flops_acc += (double)N * (double)per_point * G.flops_per_row;
+        ctx->evals_acc += (uint64_t)N * (uint64_t)per_point;
+    }
+    if (!out) return RT_OK;
     hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
                        (const double*)a.partial, N, a.E, n_sd, log((double)S), log_flag, out, out_stride);
     HIPCHK(ctx, hipGetLastError());
@@ -598,6 +614,80 @@ int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, 
     if (N > 0 && (!y_dev || !xhat_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev);
+}
+
+int rt_is_pair_count(rt_ctx* ctx, int64_t S, int64_t* E) {
+    if (!ctx || !E) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set (its width fixes the samples per pass)");
+    if (S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need 0 < S < 2^32");
+    *E = is_plan(1, S, G.nst).E;
+    return RT_OK;
+}
+
+int rt_is_pairs(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,
+                int n_sd, const double* sd_y, double scale, double df, uint64_t seed, int64_t e_lo, int64_t e_hi,
+                double* pairs) {
+    if (!ctx) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
+    if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
+    if (n_sd < 1 || n_sd > RT_MAX_SD || !sd_y) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
+    for (int k = 0; k < n_sd; ++k)
+        if (!(sd_y[k] > 0.0) || !isfinite(sd_y[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
+    const int64_t E = is_plan(1, S, G.nst).E;
+    if (e_lo < 0 || e_hi < e_lo || e_hi > E) return fail(ctx, RT_EINVAL, "need 0 <= e_lo <= e_hi <= rt_is_pair_count(S)");
+    const int64_t cnt = e_hi - e_lo;
+    if (N == 0 || cnt == 0) return RT_OK;
+    if (!y || !xhat || !pairs) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int dx = G.args.in_dim, dy = G.args.out_dim, MS = 32 * G.nst;
+    const size_t yb = (size_t)N * dy * sizeof(double), xb = (size_t)N * dx * sizeof(float);
+    int rc = ensure(ctx, ctx->b_y, yb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_xhat, xb); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_y.p, y, yb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_xhat.p, xhat, xb, hipMemcpyHostToDevice, ctx->stream));
+    // blocks of query points, bounded like rt_is_estimate's launches (sample-evals of THIS range) and to 1 GiB of pairs
+    int64_t per = ctx->max_launch_evals / (cnt * MS);
+    const int64_t per_mem = (int64_t)((1ull << 30) / ((size_t)E * n_sd * 2 * sizeof(double)));
+    if (per > per_mem) per = per_mem;
+    if (per < 1) per = 1;
+    if (per > N) per = N;
+    rc = ensure(ctx, ctx->b_partial, (size_t)per * E * n_sd * 2 * sizeof(double));
+    if (rc) return rc;
+    const size_t entry = (size_t)n_sd * 2 * sizeof(double);
+    for (int64_t n0 = 0; n0 < N; n0 += per) {
+        const int64_t nb = (N - n0 < per) ? N - n0 : per;
+        rc = is_enqueue_block(ctx, (const double*)ctx->b_y.p + n0 * dy, (const float*)ctx->b_xhat.p + n0 * dx, nullptr, nb,
+                              y_index_base + n0, S, n_sd, sd_y, scale, df, seed, 1, nullptr, 0, e_lo, e_hi);
+        if (rc) return rc;
+        // rows = query points, row = this range's cnt entries out of the E the device buffer holds per point
+        HIPCHK(ctx, hipMemcpy2DAsync(pairs + (size_t)n0 * cnt * n_sd * 2, cnt * entry,
+                                     (const char*)ctx->b_partial.p + e_lo * entry, E * entry, cnt * entry, nb,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the next block reuses the device buffer
+    }
+    return RT_OK;
+}
+
+int rt_is_merge_pairs(rt_ctx* ctx, const double* pairs, int64_t N, int64_t E, int n_sd, int64_t S, int log_flag,
+                      double* out) {
+    if (!ctx) return RT_EINVAL;
+    if (N < 0 || E < 1 || S <= 0) return fail(ctx, RT_EINVAL, "need N >= 0, E >= 1, S > 0");
+    if (n_sd < 1 || n_sd > RT_MAX_SD) return fail(ctx, RT_EINVAL, "n_sd must be in [1, RT_MAX_SD]");
+    if (N == 0) return RT_OK;
+    if (!pairs || !out) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pb = (size_t)N * E * n_sd * 2 * sizeof(double), ob = (size_t)N * n_sd * sizeof(double);
+    int rc = ensure(ctx, ctx->b_partial, pb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_out, ob); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_partial.p, pairs, pb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const double*)ctx->b_partial.p, N, E, n_sd, log((double)S), log_flag, (double*)ctx->b_out.p, N);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
 }
 
 int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,

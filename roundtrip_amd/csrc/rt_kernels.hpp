@@ -25,7 +25,9 @@ struct IsArgs {
     const double* xs;       // given samples N x S x dx, or nullptr
     double* partial;        // N x E x n_sd x 2
     int64_t N, S, y_index_base;
-    int64_t ppp;            // main passes per query point
+    int64_t ppp;            // main passes per query point in THIS launch: entries [j_lo, j_lo + ppp)
+    int64_t j_lo;           // first main pass of a point this launch runs (0 unless the samples are split over ranks)
+    int64_t left_s0;        // sample index of a point's first leftover sample (full main passes x MS)
     int64_t p_main;         // N * ppp
     int64_t p_total;        // p_main + number of leftover passes
     int64_t E;              // partial entries per query point: ppp + (rem ? 1 : 0)
@@ -136,10 +138,11 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
     const int64_t m_lo = a.p_main * (int64_t)blockIdx.x / gridDim.x, m_hi = a.p_main * ((int64_t)blockIdx.x + 1) / gridDim.x;
     const int64_t l_lo = n_left * (int64_t)blockIdx.x / gridDim.x, l_hi = n_left * ((int64_t)blockIdx.x + 1) / gridDim.x;
     const int64_t n_mine = (m_hi - m_lo) + (l_hi - l_lo);
-    // (query point, pass of that point) of the current main pass, advanced incrementally.  (Narrowing this loop state to
+    // (query point, pass of that point — an absolute entry index in [j_lo, j_lo + ppp)) of the current main pass,
+    // advanced incrementally.  (Narrowing this loop state to
     // 32 bits was tried: the register allocator then moves 21 more values between VGPRs and AGPRs inside the MLP, +0.9 %.)
     int64_t n_u = 0, j_u = 0;
-    if (m_lo < m_hi) { n_u = m_lo / a.ppp; j_u = m_lo - n_u * a.ppp; }
+    if (m_lo < m_hi) { n_u = m_lo / a.ppp; j_u = a.j_lo + (m_lo - n_u * a.ppp); }
     int64_t n_loaded = -1;                  // query point whose y / xhat sit in LDS
     auto put_x0 = [&](int d, float v) __attribute__((always_inline)) { *(float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3)) = v; };
 
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             if (!left) { r.n = n_u; r.si = j_u * MS + s_; r.valid = r.si < a.S; }
             else {
                 const int pt = s_ / a.rem, off = s_ - pt * a.rem;
-                r.n = g_u * a.q + pt; r.si = a.ppp * MS + off; r.valid = pt < a.q && r.n < a.N;
+                r.n = g_u * a.q + pt; r.si = a.left_s0 + off; r.valid = pt < a.q && r.n < a.N;
             }
             return r;
         };
@@ -245,13 +248,13 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
                     }
                     const int64_t n_o = g_u * a.q + lane;
                     if (lane < a.q && n_o < a.N) {
-                        double* dst = a.partial + 2 * ((n_o * a.E + a.ppp) * a.n_sd + k);
+                        double* dst = a.partial + 2 * ((n_o * a.E + (a.E - 1)) * a.n_sd + k);
                         dst[0] = M; dst[1] = t;
                     }
                 }
             }
         }
-        if (!left && ++j_u == a.ppp) { j_u = 0; ++n_u; }
+        if (!left && ++j_u == a.j_lo + a.ppp) { j_u = a.j_lo; ++n_u; }
     }
 #ifdef RT_STAMPS
 #if RT_STAMPS == 2

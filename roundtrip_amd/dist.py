@@ -70,3 +70,34 @@ def sharded_map(points, fn, device=None):
     lo, hi = shard_bounds(n, ws, rank)
     local = fn(points[lo:hi], lo) if hi > lo else np.zeros(0, dtype=np.float64)
     return all_gather_blocks(local, n, device)
+
+
+def all_gather_ranges(local, total, axis=1, device=None):
+    """Every rank holds the slice shard_bounds(total, world, rank) of an array along `axis`; returns the whole array on
+    every rank.  Used when ONE query point's samples are split over ranks (fewer query points than GPUs): the slices are
+    ranges of a point's (max, sum) pairs, 16 bytes each — again a single small all-gather."""
+    rank, ws = world()
+    local = np.asarray(local, dtype=np.float64)
+    if ws == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+    per = -(-int(total) // ws)
+    moved = np.moveaxis(local, axis, 0)                       # (mine, ...)
+    rest = moved.shape[1:]
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")
+    elif device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = torch.device("cuda", int(device))
+    buf = np.zeros((per,) + rest, dtype=np.float64)
+    buf[: moved.shape[0]] = moved
+    out = torch.empty((ws * per,) + rest, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(device))
+    out = out.cpu().numpy().reshape((ws, per) + rest)
+    parts = []
+    for r in range(ws):
+        lo, hi = shard_bounds(total, ws, r)
+        parts.append(out[r, : hi - lo])
+    return np.ascontiguousarray(np.moveaxis(np.concatenate(parts, axis=0), 0, axis))

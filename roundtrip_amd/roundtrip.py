@@ -36,6 +36,10 @@ class _IsModelBase(object):
     #: (rt_is_estimate_given_samples).  With identical weights this reproduces a single-threaded run of the reference
     #: up to the fp32 rounding of G; it is ~100x slower than "philox" (the host RNG) and exists for validation.
     is_sampler = "philox"
+    #: with fewer query points than ranks, split every point's SAMPLES over the ranks instead of leaving ranks idle: each
+    #: rank computes a range of a point's per-pass (max, sum) pairs, one all-gather exchanges them, every rank merges them
+    #: in the fixed order — bit-identical to the one-process answer.  None: automatic (N < world size); True / False force.
+    split_samples = None
 
     def _init_engine_state(self, device):
         self._device = device
@@ -88,11 +92,26 @@ class _IsModelBase(object):
             block = self._reference_draws_block(points, sd, scale, sample_size, df, log)
         elif self.is_sampler != "philox":
             raise ValueError("is_sampler must be 'philox' or 'numpy', not %r" % (self.is_sampler,))
-        if self.shard and dist.world()[1] > 1:
+        ws = dist.world()[1]
+        if self.shard and ws > 1 and self.is_sampler == "philox" and points.shape[0] > 0 and \
+                (self.split_samples if self.split_samples is not None else points.shape[0] < ws):
+            return self._estimate_is_split(points, [sd], scale, sample_size, df, log)[0]
+        if self.shard and ws > 1:
             return dist.sharded_map(points, block, device=eng.device)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
         return block(points, 0)
+
+    def _estimate_is_split(self, points, sds, scale, sample_size, df, log):
+        """(len(sds), N): every rank evaluates ALL query points on its range of each point's sample passes."""
+        eng = self.engine
+        rank, ws = dist.world()
+        centres = eng.mlp_forward(_lib.RT_MLP_H, points.astype(np.float32))
+        E = eng.is_pair_count(sample_size)
+        lo, hi = dist.shard_bounds(E, ws, rank)
+        mine = eng.is_pairs(points, centres, sample_size, sds, scale, lo, hi, df=df, seed=self.is_seed)
+        pairs = dist.all_gather_ranges(mine, E, axis=1, device=eng.device)
+        return eng.is_merge_pairs(pairs, sample_size, log=log)
 
     def _reference_draws_block(self, points, sd, scale, sample_size, df, log):
         """block(pts, base) for is_sampler == "numpy".  The legacy stream is sequential over ALL query points, so a

@@ -298,6 +298,34 @@ def test_sharded_map_world_size_2_gloo(tmp_path, n):
     assert res.stdout.count("rank ok") == 2
 
 
+def test_all_gather_ranges_world_size_2_gloo(tmp_path):
+    """The second sharding axis on CPU: two gloo ranks each hold their range of a query point's pairs (axis 1); the
+    gather returns the whole array on both — for a total that divides evenly, one that does not, and one smaller than
+    the world (rank 1 holds nothing)."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import torch.distributed as dist
+        from roundtrip_amd import dist as rdist
+        dist.init_process_group("gloo")
+        for total in (8, 7, 1):
+            whole = np.random.RandomState(total).standard_normal((3, total, 2, 2))
+            lo, hi = rdist.shard_bounds(total, 2, dist.get_rank())
+            got = rdist.all_gather_ranges(whole[:, lo:hi], total, axis=1)
+            assert got.shape == whole.shape and np.array_equal(got, whole), (total, got.shape)
+        dist.barrier(); dist.destroy_process_group()
+        print("rank ok")
+    """ % (ROOT,)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("rank ok") == 2
+
+
 def test_evaluate_callers_host_logic():
     """precision_at_K / create_2d_grid_data (evaluate.py:15-20, 55-59) and the callers' plumbing with a stub model."""
     from roundtrip_amd import evaluate as ev

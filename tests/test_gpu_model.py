@@ -274,6 +274,16 @@ def test_model_level_sharding_two_ranks(tmp_path):
                    CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
         for k in out:
             assert out[k].shape == one[k].shape and np.array_equal(out[k], one[k]), (k, out[k], one[k])
+        # fewer query points than ranks: the SAMPLES of the point are split over the ranks (automatic), same bits
+        m.shard = True
+        for S in (900, 650):
+            split = m.estimate_py_with_IS(y[:1], 0, sd_y=0.1, scale=0.1, sample_size=S, save=False)
+            m.shard = False
+            alone = m.estimate_py_with_IS(y[:1], 0, sd_y=0.1, scale=0.1, sample_size=S, save=False)
+            m.shard = True
+            assert np.array_equal(split, alone), (S, split, alone)
+        m.split_samples = True                                        # forced, with more points than ranks
+        assert np.array_equal(m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False), one["IS"])
         dist.barrier(); dist.destroy_process_group()
         print("rank ok")
     """ % (root,)))

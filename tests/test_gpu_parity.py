@@ -476,6 +476,33 @@ def test_jacobian_golden(engine, name):
     assert np.abs(J - f["jac_at_xhat"]).max() <= 1e-5 * np.abs(f["jac_at_xhat"]).max()
 
 
+@pytest.mark.parametrize("S", [1000, 1024, 650, 37, 40000])
+def test_pair_ranges_merge_to_the_estimate(engine, make_nets, S):
+    """rt_is_pairs over any split of a point's E pairs + rt_is_merge_pairs == rt_is_estimate_multi, bit for bit: what lets
+    ranks split ONE query point's samples (second axis).  S with packed leftovers (1000 = 15 x 64 + 40 is
+    not packed, 650 and 37 are), a whole number of passes, and the reference's 40000."""
+    gw, gb, hw, hb = make_nets(3, 6)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    y = np.random.RandomState(9).standard_normal((3, 6)) * 0.1
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    sds = [0.1, 0.4]
+    kw = dict(df=1.0, seed=5, y_index_base=17)
+    E = engine.is_pair_count(S)
+    assert E == S // 64 + (1 if S % 64 else 0)
+    cuts = sorted(set([0, E // 3, E // 3, (2 * E) // 3, E - 1, E]))
+    parts = [engine.is_pairs(y, xhat, S, sds, 0.1, lo, hi, **kw) for lo, hi in zip(cuts, cuts[1:])]
+    pairs = np.concatenate(parts, axis=1)
+    assert pairs.shape == (3, E, 2, 2)
+    assert np.array_equal(pairs, engine.is_pairs(y, xhat, S, sds, 0.1, 0, E, **kw))
+    assert engine.is_pairs(y, xhat, S, sds, 0.1, 2 if E > 2 else 0, 2 if E > 2 else 0, **kw).shape[1] == 0      # empty range
+    for log in (True, False):
+        want = engine.is_estimate_multi(y, xhat, S, sds, 0.1, log=log, **kw)
+        assert np.array_equal(engine.is_merge_pairs(pairs, S, log=log), want)
+    with pytest.raises(_lib.RtError):
+        engine.is_pairs(y, xhat, S, sds, 0.1, 0, E + 1, **kw)
+
+
 def _random_case(rng):
     n_hidden = int(rng.randint(1, 5))
     top = int(rng.choice([128, 256, 512, 512, 1024]))
