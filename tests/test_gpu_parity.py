@@ -248,6 +248,9 @@ def test_large_calls_split_into_bounded_launches(engine, make_nets, monkeypatch)
         sds = [0.05, 0.3, 1.0]
         assert np.array_equal(small.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3),
                               engine.is_estimate_multi(y, xhat, S, sds, 0.1, 1.0, seed=3))
+        E = engine.is_pair_count(S)                          # pair ranges are computed in blocks of query points too
+        assert np.array_equal(small.is_pairs(y, xhat, S, sds, 0.1, 2, E, seed=3),
+                              engine.is_pairs(y, xhat, S, sds, 0.1, 2, E, seed=3))
         xs = engine.draw_samples(xhat, S, 0.1, 1.0, seed=3).astype(np.float64)
         assert np.array_equal(small.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False),
                               engine.is_estimate_given_samples(y, xhat, xs, 0.3, 0.1, 1.0, log=False))
