@@ -29,6 +29,7 @@ __global__ __launch_bounds__(512) void bench(float* out, int iters, unsigned lon
     for (int i = 0; i < 16; ++i) v[i] = threadIdx.x + i;
     for (int i = 0; i < 8; ++i) pv[i] = f32x2{v[i], v[i + 8]};
     const unsigned lp = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
+    const unsigned lp4 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 4;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -51,6 +52,9 @@ __global__ __launch_bounds__(512) void bench(float* out, int iters, unsigned lon
                 if (KIND == 6) asm volatile("s_nop 0");
                 if (KIND == 7) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ld[k & 3]) : "v"(gp), "n"(1024 * (k & 3)));
                 if (KIND == 8) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[k & 3]) : "v"(lp), "n"(4096 * (k & 7)));
+                // KIND 11: ds_max_f32 (LDS float max, no return) on the lane's own dword; 12: ds_write_b32 for comparison
+                if (KIND == 11) asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(lp4), "v"(v[j]), "n"(2048 * (k & 7)));
+                if (KIND == 12) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(lp4), "v"(v[j]), "n"(2048 * (k & 7)));
                 // KIND 9: the same K VALU instructions per MFMA on average, but in ONE cluster after every 8 MFMAs
                 if (KIND == 10 && i == 7) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
             }
@@ -92,7 +96,7 @@ void run(const char* name, float* out, unsigned long long* cyc) {
     printf("%-28s K=%2d : %.2f ticks per MFMA (1 wave/SIMD)   %.2f (2 waves/SIMD)\n", name, K, r[0], r[1]);
 }
 
-int main() {
+int main(int argc, char** argv) {
     float* out;
     unsigned long long* cyc;
     hipMalloc(&out, 256 * 512 * 4);
@@ -100,6 +104,17 @@ int main() {
     hipMalloc(&g_w, (size_t)256 * 512 * 16 + 8192);
     hipMemset(g_w, 0, (size_t)256 * 512 * 16 + 8192);
     run<0, 0>("mfma only", out, cyc);
+    if (argc > 1) {   // "lds": could the leaky-ReLU's max run in the LDS, behind the MFMAs? (DESIGN.md ledger)
+        run<1, 12>("ds_write_b32", out, cyc);
+        run<4, 12>("ds_write_b32", out, cyc);
+        run<1, 11>("ds_max_f32", out, cyc);
+        run<2, 11>("ds_max_f32", out, cyc);
+        run<4, 11>("ds_max_f32", out, cyc);
+        run<5, 11>("ds_max_f32", out, cyc);
+        run<8, 11>("ds_max_f32", out, cyc);
+        hipDeviceSynchronize();
+        return 0;
+    }
     run<1, 7>("global_load_dwordx4", out, cyc);
     run<2, 7>("global_load_dwordx4", out, cyc);
     run<1, 8>("ds_read_b128", out, cyc);
