@@ -218,9 +218,8 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
         scr[p * MS + s] = se;
         scr[NTHREADS + p * MS + s] = lw;
         __syncthreads();
-        // ---- D. this pass's log-sum-exp pairs (wave 1, lane = sample slot: wave 0 goes straight on to the next
-        //         pass's sampler, so the two phases overlap instead of adding up) -------------------------------------
-        if (wave == 1) {
+        // ---- D. this pass's log-sum-exp pairs (wave 0; lane = sample slot) ----------------------
+        if (wave == 0) {
             double se_t = 0.0, lw_t = 0.0;
             if (lane < MS) {
                 se_t = scr[lane]; lw_t = scr[NTHREADS + lane];
