@@ -22,6 +22,7 @@
 #ifndef RT_IS_H
 #define RT_IS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -34,12 +35,15 @@ extern "C" {
 #define RT_ENOTSET       3   /* the MLP needed by the call has not been set */
 #define RT_EUNSUPPORTED  4   /* shape outside what the kernels handle */
 #define RT_ENOMEM        5
+#define RT_ETOOBIG       6   /* the call needs more than a fixed-size buffer holds */
+#define RT_ECOMM         7   /* RCCL could not be loaded, or one of its calls failed */
 
 #define RT_MLP_G 0           /* generator  G: x (dx) -> y (dy)  : g_net, main_density_est.py:447 */
 #define RT_MLP_H 1           /* encoder    H: y (dy) -> x (dx)  : h_net / e_net, main_density_est.py:448 */
 
 #define RT_MAX_LAYERS 24
 #define RT_MAX_SD 8          /* sd_y values one rt_is_estimate_multi call can score */
+#define RT_COMM_ID_BYTES 128 /* size of the rendezvous token of rt_comm_unique_id / rt_comm_init */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -133,6 +137,13 @@ int rt_is_estimate_given_samples(rt_ctx* ctx, const double* y, const float* xhat
 int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_base, int64_t S,
                     double scale, double df, uint64_t seed, float* x_samples);
 
+/* The sampler's counter-based generator on caller-chosen words, so that it can be pinned to the published algorithm
+ * (Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11; known-answer
+ * vectors of the Random123 distribution): ctr_key is n x 6 uint32 (counter words 0..3, key words 0..1), out n x 4.
+ * rt_draw_samples calls it with counter = (sample index, call index, y index lo, y index hi), key = seed (lo, hi).
+ * Replaces numpy's MT19937 behind np.random.chisquare / multivariate_normal (main_density_est.py:267,316-317). */
+int rt_philox4x32_10(rt_ctx* ctx, const uint32_t* ctr_key, int64_t n, uint32_t* out);
+
 /* Device-resident variant of rt_is_estimate: y_dev, xhat_dev, out_dev are DEVICE pointers on the
  * context's device.  Enqueues on the context's stream and returns without waiting; call rt_sync()
  * before reading out_dev from another stream or the host. */
@@ -176,6 +187,36 @@ int rt_reset_counters(rt_ctx* ctx);
 
 /* Device facts the host side needs for work partitioning. */
 int rt_device_cu_count(rt_ctx* ctx, int* out);
+
+/* --- Device memory for callers of the *_dev entry points (the reference keeps its arrays in numpy and feeds TF
+ * placeholders, main_density_est.py:232,247; a host program that wants its query points resident in HBM needs no other
+ * GPU library than this one).  rt_dev_free waits for the context's stream first; the copies are synchronous. */
+int rt_dev_alloc(rt_ctx* ctx, size_t bytes, void** out_dev);
+int rt_dev_free(rt_ctx* ctx, void* ptr_dev);
+int rt_memcpy_h2d(rt_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
+int rt_memcpy_d2h(rt_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+
+/* --- The final gather over GPUs ----------------------------------------------------------------------
+ * Query points shard over ranks with no data-path collective; the one exchange is the all-gather that assembles the
+ * N results (replaces nothing: the reference's loop over points, main_density_est.py:324, is serial; the nearest
+ * analogue is the `np.array([...])` that collects the per-point values at :342).  It runs on RCCL, on the context's
+ * stream; librccl.so.1 is dlopen'ed by the first rt_comm_* call (RT_RCCL_LIB overrides the name), so one-GPU processes
+ * never load it.  One communicator per context; one rank per GPU.
+ *   rt_comm_unique_id   rank 0 makes the RT_COMM_ID_BYTES rendezvous token and hands it to the other ranks by any
+ *                       means (roundtrip_amd/dist.py: a TCP exchange on MASTER_ADDR)
+ *   rt_comm_init        collective over all nranks ranks
+ *   rt_comm_all_gather_f64      recv[r*count + i] = rank r's send[i]; host buffers, synchronous
+ *   rt_comm_all_gather_f64_dev  the same on device buffers, asynchronous on the context's stream (after the estimate
+ *                       enqueued there: no host round trip between kernel and gather)
+ *   rt_comm_all_reduce_max_f64  in place, host buffer (bench.py's max-over-ranks time); rt_comm_barrier = one of them */
+int rt_comm_unique_id(void* id128);
+int rt_comm_init(rt_ctx* ctx, int nranks, int rank, const void* id128);
+int rt_comm_destroy(rt_ctx* ctx);
+int rt_comm_info(rt_ctx* ctx, int* rank, int* nranks);
+int rt_comm_all_gather_f64(rt_ctx* ctx, const double* send, int64_t count, double* recv);
+int rt_comm_all_gather_f64_dev(rt_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev);
+int rt_comm_all_reduce_max_f64(rt_ctx* ctx, double* values, int64_t count);
+int rt_comm_barrier(rt_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,8 @@ def _load():
     lib.rto_is_estimate_given_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                   C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
                                                   C.c_int, C.c_int, C.c_void_p]
+    lib.rto_philox4x32_10.restype = None
+    lib.rto_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rto_draw_samples.restype = C.c_int
     lib.rto_draw_samples.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_double,
                                      C.c_double, C.c_uint64, C.c_void_p]
@@ -124,3 +126,12 @@ def draw_samples(xhat, y_index_base, S, scale, df, seed):
     if rc:
         raise RuntimeError("rto_draw_samples: unsupported df")
     return xs
+
+
+def philox4x32_10(ctr, key):
+    """The four output words of Philox4x32-10 for one (counter[4], key[2])."""
+    c = np.ascontiguousarray(ctr, dtype=np.uint32).reshape(4)
+    k = np.ascontiguousarray(key, dtype=np.uint32).reshape(2)
+    out = np.empty(4, dtype=np.uint32)
+    lib().rto_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out

@@ -366,7 +366,7 @@ int rto_is_estimate_given_samples(void* gp, const double* y, const float* xhat, 
  * This repo's proposal sampler (rt_is.hip draw_sample), restated: Philox4x32-10 keyed by the seed,
  * counter (sample index, call index, y index lo, y index hi); call c yields normals g[4c..4c+3] by two
  * float32 Box-Muller transforms; chi2 = g[0]^2+..+g[ndf-1]^2 for integer df <= 32;
- * x_d = xhat_d + scale*g[ndf+d]/sqrt(chi2/df).  libm's logf/sincosf may differ from the GPU's in the
+ * x_d = xhat_d + scale*g[ndf+d]/sqrt(chi2/df); any other df: chi2_over_df_gamma below.  libm's logf/sincosf may differ from the GPU's in the
  * last ulp, so agreement with the GPU draws is to a few ulp, not bitwise.
  * --------------------------------------------------------------------------------------------- */
 static void philox(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -378,7 +378,14 @@ static void philox(uint32_t c[4], uint32_t k0, uint32_t k1) {
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-static float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+/* Philox4x32-10 on raw words, for the known-answer test against the published Random123 vectors
+ * (Salmon et al., SC'11; kat_vectors of the Random123 distribution): out = philox4x32_10(ctr, key). */
+void rto_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox(c, key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+static float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); } /* (k+1/2)/2^23: exact, in (0,1) */
 static void box_muller(uint32_t a, uint32_t b, float* n0, float* n1) {
     const float r = sqrtf(-2.0f * logf(u01(a)));
     const float th = 6.28318530717958647692f * u01(b);
@@ -386,15 +393,47 @@ static void box_muller(uint32_t a, uint32_t b, float* n0, float* n1) {
     *n1 = r * sinf(th);
 }
 
+/* chi2(df)/df for a df that is not an integer in [1, 32] (rt_sampler.hpp chi2_over_df_gamma): chi2 = 2*Gamma(df/2, 1)
+ * by Marsaglia & Tsang (2000), float32 throughout, on Philox calls 0x40000000, 0x40000001, ... of the sample: shape < 1
+ * takes one call for the boost u^(1/shape) and continues with shape + 1; every further call is one proposal
+ * (z from words 0 and 1 by Box-Muller, u from word 2), accepted when log u < z^2/2 + d - d v + d log v. */
+static float chi2_over_df_gamma(float df, uint32_t i, uint32_t ylo, uint32_t yhi, uint32_t k0, uint32_t k1) {
+    float shape = 0.5f * df, boost = 1.0f;
+    uint32_t call = 0x40000000u;
+    if (shape < 1.0f) {
+        uint32_t c[4] = {i, call++, ylo, yhi};
+        philox(c, k0, k1);
+        boost = powf(u01(c[0]), 1.0f / shape);
+        shape += 1.0f;
+    }
+    const float d = shape - (1.0f / 3.0f), cc = 1.0f / sqrtf(9.0f * d);
+    float g = d;
+    for (int it = 0; it < 64; ++it) {
+        uint32_t c[4] = {i, call++, ylo, yhi};
+        philox(c, k0, k1);
+        float z, unused;
+        box_muller(c[0], c[1], &z, &unused);
+        float v = 1.0f + cc * z;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        const float u = u01(c[2]);
+        if (logf(u) < 0.5f * z * z + d - d * v + d * logf(v)) { g = d * v; break; }
+    }
+    return 2.0f * g * boost / df;
+}
+
 int rto_draw_samples(const float* xhat, int64_t N, int64_t y_index_base, int64_t S, int dx, double scale,
                      double df, uint64_t seed, float* xs) {
-    if (!(df == floor(df) && df >= 1.0 && df <= 32.0)) return 1; /* gamma path not restated */
-    const int ndf = (int)df;
+    if (!(df > 0.0)) return 1;
+    const int ndf = (df == floor(df) && df <= 32.0) ? (int)df : 0;   /* 0: the gamma path */
     const float fscale = (float)scale, fdf = (float)df;
     for (int64_t n = 0; n < N; ++n)
         for (int64_t i = 0; i < S; ++i) {
             const uint64_t yi = (uint64_t)(y_index_base + n);
             float zsum = 0.0f, mult = 0.0f;
+            if (ndf == 0)
+                mult = fscale / sqrtf(chi2_over_df_gamma(fdf, (uint32_t)i, (uint32_t)yi, (uint32_t)(yi >> 32),
+                                                         (uint32_t)seed, (uint32_t)(seed >> 32)));
             const int total = ndf + dx;
             for (int c = 0; 4 * c < total; ++c) {
                 uint32_t ctr[4] = {(uint32_t)i, (uint32_t)c, (uint32_t)yi, (uint32_t)(yi >> 32)};

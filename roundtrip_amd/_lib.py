@@ -20,7 +20,15 @@ SYMBOLS = (
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
     "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs",
+    "rt_philox4x32_10",
+    "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h",
+    "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
+    "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
 )
+
+RT_ETOOBIG = 6
+RT_ECOMM = 7
+RT_COMM_ID_BYTES = 128
 
 
 class RtCounters(C.Structure):
@@ -29,7 +37,9 @@ class RtCounters(C.Structure):
 
 
 class RtError(RuntimeError):
-    pass
+    def __init__(self, msg, code=None):
+        RuntimeError.__init__(self, msg)
+        self.code = code
 
 
 _lib = None
@@ -68,6 +78,19 @@ def load():
     lib.rt_is_pair_count.argtypes = [vp, i64, C.POINTER(i64)]
     lib.rt_is_pairs.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, dbl, dbl, C.c_uint64, i64, i64, vp]
     lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
+    lib.rt_philox4x32_10.argtypes = [vp, vp, i64, vp]
+    lib.rt_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.rt_dev_free.argtypes = [vp, vp]
+    lib.rt_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rt_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rt_comm_unique_id.argtypes = [vp]
+    lib.rt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.rt_comm_destroy.argtypes = [vp]
+    lib.rt_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rt_comm_all_gather_f64.argtypes = [vp, vp, i64, vp]
+    lib.rt_comm_all_gather_f64_dev.argtypes = [vp, vp, i64, vp]
+    lib.rt_comm_all_reduce_max_f64.argtypes = [vp, vp, i64]
+    lib.rt_comm_barrier.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name != "rt_last_error":
@@ -99,7 +122,7 @@ class Engine(object):
 
     def _chk(self, rc):
         if rc:
-            raise RtError("librt_is error %d: %s" % (rc, self._lib.rt_last_error(self._h).decode()))
+            raise RtError("librt_is error %d: %s" % (rc, self._lib.rt_last_error(self._h).decode()), rc)
 
     def set_mlp(self, which, weights, biases, alpha=0.2):
         ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
@@ -150,7 +173,8 @@ class Engine(object):
             raise RtError("G has not been set")
         return dims[0], dims[-1]
 
-    def is_estimate(self, y, xhat, sample_size, sd_y, scale, df=1.0, seed=0, log=True, y_index_base=0):
+    def _points(self, y, xhat):
+        """(y float64 (N, dy), xhat float32 (N, dx), N, dx), contiguous and shape-checked against the G that is set."""
         dx, dy = self._g_dims()
         y = np.ascontiguousarray(y, dtype=np.float64)
         if y.ndim != 2 or y.shape[1] != dy:
@@ -159,6 +183,10 @@ class Engine(object):
         xhat = np.ascontiguousarray(xhat, dtype=np.float32)
         if xhat.shape != (N, dx):
             raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        return y, xhat, N, dx
+
+    def is_estimate(self, y, xhat, sample_size, sd_y, scale, df=1.0, seed=0, log=True, y_index_base=0):
+        y, xhat, N, dx = self._points(y, xhat)
         out = np.empty(N, dtype=np.float64)
         self._chk(self._lib.rt_is_estimate(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
                                            int(sample_size), float(sd_y), float(scale), float(df),
@@ -167,14 +195,7 @@ class Engine(object):
 
     def is_estimate_multi(self, y, xhat, sample_size, sd_ys, scale, df=1.0, seed=0, log=True, y_index_base=0):
         """One sampler + G pass scored for every sd in sd_ys; returns (len(sd_ys), N)."""
-        dx, dy = self._g_dims()
-        y = np.ascontiguousarray(y, dtype=np.float64)
-        if y.ndim != 2 or y.shape[1] != dy:
-            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
-        N = y.shape[0]
-        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
-        if xhat.shape != (N, dx):
-            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        y, xhat, N, dx = self._points(y, xhat)
         sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
         out = np.empty((sds.size, N), dtype=np.float64)
         self._chk(self._lib.rt_is_estimate_multi(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
@@ -191,14 +212,7 @@ class Engine(object):
 
     def is_pairs(self, y, xhat, sample_size, sd_ys, scale, e_lo, e_hi, df=1.0, seed=0, y_index_base=0):
         """Pairs [e_lo, e_hi) of every query point: (N, e_hi - e_lo, len(sd_ys), 2) float64."""
-        dx, dy = self._g_dims()
-        y = np.ascontiguousarray(y, dtype=np.float64)
-        if y.ndim != 2 or y.shape[1] != dy:
-            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
-        N = y.shape[0]
-        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
-        if xhat.shape != (N, dx):
-            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        y, xhat, N, dx = self._points(y, xhat)
         sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
         out = np.empty((N, max(0, int(e_hi) - int(e_lo)), sds.size, 2), dtype=np.float64)
         self._chk(self._lib.rt_is_pairs(self._h, y.ctypes.data, xhat.ctypes.data, C.c_int64(N),
@@ -220,14 +234,7 @@ class Engine(object):
         return out
 
     def is_estimate_given_samples(self, y, xhat, x_samples, sd_y, scale, df=1.0, log=True):
-        dx, dy = self._g_dims()
-        y = np.ascontiguousarray(y, dtype=np.float64)
-        if y.ndim != 2 or y.shape[1] != dy:
-            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
-        N = y.shape[0]
-        xhat = np.ascontiguousarray(xhat, dtype=np.float32)
-        if xhat.shape != (N, dx):
-            raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
+        y, xhat, N, dx = self._points(y, xhat)
         xs = np.ascontiguousarray(x_samples, dtype=np.float64)
         if xs.ndim != 3 or xs.shape[0] != N or xs.shape[2] != dx or xs.shape[1] < 1:
             raise ValueError("expected x_samples of shape (%d, S, %d), got %r" % (N, dx, xs.shape))
@@ -249,12 +256,80 @@ class Engine(object):
                                             xs.ctypes.data))
         return xs
 
+    def philox4x32_10(self, ctr_key):
+        """(n, 4) uint32 outputs of the sampler's generator for (n, 6) uint32 rows (counter[4], key[2])."""
+        ck = np.ascontiguousarray(ctr_key, dtype=np.uint32).reshape(-1, 6)
+        out = np.empty((ck.shape[0], 4), dtype=np.uint32)
+        self._chk(self._lib.rt_philox4x32_10(self._h, ck.ctypes.data, ck.shape[0], out.ctypes.data))
+        return out
+
     # ---- device-resident entry points (pointers are raw device addresses, e.g. torch .data_ptr()) ----
     def is_estimate_dev(self, y_ptr, xhat_ptr, N, sample_size, sd_y, scale, out_ptr, df=1.0, seed=0,
                         log=True, y_index_base=0):
         self._chk(self._lib.rt_is_estimate_dev(self._h, y_ptr, xhat_ptr, int(N), int(y_index_base),
                                                int(sample_size), float(sd_y), float(scale), float(df),
                                                int(seed), int(bool(log)), out_ptr))
+
+    # ---- device memory (rt_dev_alloc & co.): what callers of the *_dev entry points keep their arrays in ----
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self._lib.rt_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        if ptr and getattr(self, "_h", None):
+            self._chk(self._lib.rt_dev_free(self._h, ptr))
+
+    def to_device(self, arr):
+        """A fresh device copy of a numpy array; returns the raw device address (free it with dev_free)."""
+        arr = np.ascontiguousarray(arr)
+        ptr = self.dev_alloc(arr.nbytes)
+        self._chk(self._lib.rt_memcpy_h2d(self._h, ptr, arr.ctypes.data, arr.nbytes))
+        return ptr
+
+    def from_device(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self._lib.rt_memcpy_d2h(self._h, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    # ---- the final gather over GPUs: RCCL behind the C ABI (rt_comm_*) ----
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(RT_COMM_ID_BYTES)
+        rc = self._lib.rt_comm_unique_id(buf)
+        if rc:
+            raise RtError("rt_comm_unique_id failed (%d): %s" % (rc, self._lib.rt_last_error(None).decode()), rc)
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        if len(unique_id) != RT_COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % RT_COMM_ID_BYTES)
+        self._chk(self._lib.rt_comm_init(self._h, int(nranks), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        self._chk(self._lib.rt_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, n = C.c_int(), C.c_int()
+        self._chk(self._lib.rt_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def comm_all_gather(self, local):
+        """(nranks, len(local)) float64: every rank's `local` (all of one length), through RCCL."""
+        local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1)
+        out = np.empty((self.comm_info()[1], local.size), dtype=np.float64)
+        self._chk(self._lib.rt_comm_all_gather_f64(self._h, local.ctypes.data, local.size, out.ctypes.data))
+        return out
+
+    def comm_all_gather_dev(self, send_ptr, count, recv_ptr):
+        self._chk(self._lib.rt_comm_all_gather_f64_dev(self._h, send_ptr, int(count), recv_ptr))
+
+    def comm_all_reduce_max(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
+        self._chk(self._lib.rt_comm_all_reduce_max_f64(self._h, v.ctypes.data, v.size))
+        return v
+
+    def comm_barrier(self):
+        self._chk(self._lib.rt_comm_barrier(self._h))
 
     def mlp_forward_dev(self, which, in_ptr, N, out_ptr):
         self._chk(self._lib.rt_mlp_forward_dev(self._h, int(which), in_ptr, int(N), out_ptr))

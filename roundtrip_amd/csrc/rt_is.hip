@@ -27,6 +27,9 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 (573 MB) is dlopen'ed by rt_comm_init, never linked
 
 #include "../../include/rt_is.h"
 
@@ -66,11 +69,14 @@ struct rt_ctx {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     HostMlp mlp[2];
-    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout;
+    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout, b_csend, b_crecv;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<const void*, int>> lds_allowed;   // kernels whose dynamic-LDS limit has been raised, and to what
     size_t events_used = 0;
     double ms_harvested = 0.0;              // durations already folded in by harvest_events()
     uint64_t launches_harvested = 0;
+    ncclComm_t comm = nullptr;              // rt_comm_init
+    int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
     double flops_acc = 0.0;
     uint64_t evals_acc = 0;
@@ -145,10 +151,24 @@ void free_mlp(HostMlp& m) {
     m.set = false;
 }
 
+// Raises a kernel's dynamic-LDS limit to `lds` bytes, once per (context, kernel): the attribute is per device and
+// sticky, and a context stays on one device, so only growth needs another hipFuncSetAttribute.
+hipError_t allow_lds(rt_ctx* ctx, const void* fn, int lds) {
+    for (auto& kv : ctx->lds_allowed)
+        if (kv.first == fn) {
+            if (kv.second >= lds) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) kv.second = lds;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) ctx->lds_allowed.emplace_back(fn, lds);
+    return e;
+}
+
 template <int HID, int NST, bool GIVEN, bool SHARE>
 int launch_is_variant(rt_ctx* ctx, const IsArgs& a, int grid, int lds) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)is_fused_kernel<HID, NST, GIVEN, SHARE>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(ctx, allow_lds(ctx, (const void*)is_fused_kernel<HID, NST, GIVEN, SHARE>, lds));
     hipLaunchKernelGGL((is_fused_kernel<HID, NST, GIVEN, SHARE>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
@@ -166,8 +186,7 @@ int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
 
 template <int HID, int NST>
 int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* out, int grid, int lds) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_fwd_kernel<HID, NST>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_fwd_kernel<HID, NST>, lds));
     hipLaunchKernelGGL((mlp_fwd_kernel<HID, NST>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, out);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
@@ -175,8 +194,7 @@ int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float*
 
 template <int HID>
 int launch_jvp(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)mlp_jvp_kernel<HID>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_kernel<HID>, lds));
     hipLaunchKernelGGL((mlp_jvp_kernel<HID>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, yout, J);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
@@ -216,11 +234,20 @@ size_t is_partial_bytes(int64_t N, int64_t S, int nst, int n_sd) {
     return (size_t)N * (size_t)is_plan(N, S, nst).E * n_sd * 2 * sizeof(double);
 }
 
+// Where a launch's per-pass pairs go, and whether the launch is bracketed by HIP events for rt_get_counters: the
+// context's own buffer (timed), or the device's `scratch` array for rt_is_estimate_dev_noalloc (untimed — creating an
+// event allocates).
+struct PairBuf {
+    double* p;
+    size_t cap;
+    bool timed;
+};
+
 // Enqueues one launch of the fused kernel for N query points, computing the pairs [e_lo, e_hi) of every point into
-// ctx->b_partial (laid out N x E x n_sd x 2 whatever the range; e_hi < 0 means all E), and — when out is not NULL — the
+// pb.p (laid out N x E x n_sd x 2 whatever the range; e_hi < 0 means all E), and — when out is not NULL — the
 // finalize kernel whose results go to out[k*out_stride + n] (only meaningful for the full range).
 // All pointers are device pointers.
-int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
+int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const float* xhat, const double* xs, int64_t N,
                      int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
                      uint64_t seed, int log_flag, double* out, int64_t out_stride,
                      int64_t e_lo = 0, int64_t e_hi = -1) {
@@ -247,9 +274,9 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
     a.N = N; a.S = S; a.y_index_base = y_index_base;
     a.y = y; a.xhat = xhat; a.xs = xs;
     a.n_sd = n_sd;
-    if (is_partial_bytes(N, S, nst, n_sd) > ctx->b_partial.cap)
+    if (is_partial_bytes(N, S, nst, n_sd) > pb.cap)
         return fail(ctx, RT_EINVAL, "internal: partial-result buffer smaller than the block needs");
-    a.partial = (double*)ctx->b_partial.p;
+    a.partial = pb.p;
     const double PI = 3.14159265358979323846;
     const double ct = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * PI) - log(scale);
     for (int k = 0; k < n_sd; ++k) {
@@ -263,18 +290,19 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
 
     const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy);
     const int grid = (int)((a.p_total < grid_max) ? a.p_total : grid_max);
-    if (ctx->events_used == MAX_EVENT_PAIRS) {
-        rc = harvest_events(ctx);
-        if (rc) return rc;
+    if (pb.timed) {
+        if (ctx->events_used == MAX_EVENT_PAIRS) {
+            rc = harvest_events(ctx);
+            if (rc) return rc;
+        }
+        if (ctx->events_used == ctx->events.size()) {
+            hipEvent_t e0, e1;
+            HIPCHK(ctx, hipEventCreate(&e0));
+            HIPCHK(ctx, hipEventCreate(&e1));
+            ctx->events.emplace_back(e0, e1);
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used].first, ctx->stream));
     }
-    if (ctx->events_used == ctx->events.size()) {
-        hipEvent_t e0, e1;
-        HIPCHK(ctx, hipEventCreate(&e0));
-        HIPCHK(ctx, hipEventCreate(&e1));
-        ctx->events.emplace_back(e0, e1);
-    }
-    auto& ev = ctx->events[ctx->events_used];
-    HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
     const bool given = xs != nullptr;
     switch (G.hid * 10 + nst) {
         case 1282: rc = launch_is<128, 2>(ctx, a, given, grid, cv.total); break;
@@ -284,9 +312,9 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
     if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
-    ctx->events_used++;
-    {   // sample-evals of this launch (the whole of S unless the call covers a range of a point's passes)
+    if (pb.timed) {   // sample-evals of this launch (the whole of S unless the call covers a range of a point's passes)
+        HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used].second, ctx->stream));
+        ctx->events_used++;
         int64_t per_point = cnt * MS + (do_left ? pl.rem : 0);
         if (pl.rem == 0 && cnt && e_lo + cnt == pl.ppp) per_point -= pl.ppp * MS - S;   // the part-full last main pass
         ctx->flops_acc += (double)N * (double)per_point * G.flops_per_row;
@@ -303,9 +331,12 @@ int is_enqueue_block(rt_ctx* ctx, const double* y, const float* xhat, const doub
 // ctx->max_launch_evals sample-evals (about 8 s of one MI355X by default), so that a 10^10-eval call (BASELINE config 3's
 // share of one GPU) is a sequence of bounded kernels rather than one that runs for minutes.  Query points are
 // independent and the sampler is keyed by the global index, so the split does not change any draw.
+// fixed == nullptr: the pairs go to the context's own buffer, grown (hipMalloc) to the largest block.
+// fixed != nullptr (rt_is_estimate_dev_noalloc): they go to that buffer, the call is refused if the pairs of ALL its
+// query points exceed fixed->cap, and nothing on this path allocates (no hipMalloc / hipFree / hipEventCreate).
 int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
                int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
-               uint64_t seed, int log_flag, double* out) {
+               uint64_t seed, int log_flag, double* out, const PairBuf* fixed = nullptr) {
     HostMlp& G = ctx->mlp[RT_MLP_G];
     if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
     if (N < 0 || S <= 0 || S > 0xFFFFFFFFll) return fail(ctx, RT_EINVAL, "need N >= 0 and 0 < S < 2^32");
@@ -314,6 +345,8 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
         if (!(sd_ys[k] > 0.0) || !isfinite(sd_ys[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
     if (N == 0) return RT_OK;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
+    if (fixed && (size_t)N > fixed->cap / is_partial_bytes(1, S, G.nst, n_sd))
+        return fail(ctx, RT_ETOOBIG, "the pairs of this call exceed the fixed pair buffer");
     int64_t per = ctx->max_launch_evals / S;
     {   // ... and to 1 GiB of per-pass partial results (16 B per pass and sd value; only matters for tiny S)
         const int64_t per_mem = (int64_t)((1ull << 30) / is_partial_bytes(1, S, G.nst, n_sd));
@@ -324,7 +357,7 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     per = (N + nblocks - 1) / nblocks;           // balanced blocks
     // the partial-result buffer is sized ONCE for the largest block, before anything is enqueued: growing it between
     // two launches of one call would free memory the previous launch may still be writing
-    {
+    if (!fixed) {
         size_t need = 0;
         for (int64_t n0 = 0; n0 < N; n0 += per) {
             const int64_t nb = (N - n0 < per) ? N - n0 : per;
@@ -334,9 +367,11 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
         const int rc = ensure(ctx, ctx->b_partial, need);
         if (rc) return rc;
     }
+    // (blocks of one call reuse the buffer from its start: they run in stream order)
+    const PairBuf pb = fixed ? *fixed : PairBuf{(double*)ctx->b_partial.p, ctx->b_partial.cap, true};
     for (int64_t n0 = 0; n0 < N; n0 += per) {
         const int64_t nb = (N - n0 < per) ? N - n0 : per;
-        const int rc = is_enqueue_block(ctx, y + n0 * dy, xhat + n0 * dx, xs ? xs + (size_t)n0 * S * dx : nullptr, nb,
+        const int rc = is_enqueue_block(ctx, pb, y + n0 * dy, xhat + n0 * dx, xs ? xs + (size_t)n0 * S * dx : nullptr, nb,
                                         y_index_base + n0, S, n_sd, sd_ys, scale, df, seed, log_flag, out + n0, N);
         if (rc) return rc;
     }
@@ -406,6 +441,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
+    ctx->lds_allowed.reserve(64);    // so that no launch path grows it (rt_is_estimate_dev_noalloc allocates nothing)
     *out = ctx;
     return RT_OK;
 }
@@ -414,9 +450,11 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)rt_comm_destroy(ctx);
     free_mlp(ctx->mlp[0]);
     free_mlp(ctx->mlp[1]);
-    DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout};
+    DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout,
+                      &ctx->b_csend, &ctx->b_crecv};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
@@ -658,7 +696,8 @@ int rt_is_pairs(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int6
     const size_t entry = (size_t)n_sd * 2 * sizeof(double);
     for (int64_t n0 = 0; n0 < N; n0 += per) {
         const int64_t nb = (N - n0 < per) ? N - n0 : per;
-        rc = is_enqueue_block(ctx, (const double*)ctx->b_y.p + n0 * dy, (const float*)ctx->b_xhat.p + n0 * dx, nullptr, nb,
+        rc = is_enqueue_block(ctx, PairBuf{(double*)ctx->b_partial.p, ctx->b_partial.cap, true},
+                              (const double*)ctx->b_y.p + n0 * dy, (const float*)ctx->b_xhat.p + n0 * dx, nullptr, nb,
                               y_index_base + n0, S, n_sd, sd_y, scale, df, seed, 1, nullptr, 0, e_lo, e_hi);
         if (rc) return rc;
         // rows = query points, row = this range's cnt entries out of the E the device buffer holds per point
@@ -716,6 +755,24 @@ int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_b
     return RT_OK;
 }
 
+int rt_philox4x32_10(rt_ctx* ctx, const uint32_t* ctr_key, int64_t n, uint32_t* out) {
+    if (!ctx) return RT_EINVAL;
+    if (n < 0) return fail(ctx, RT_EINVAL, "n < 0");
+    if (n == 0) return RT_OK;
+    if (!ctr_key || !out) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t ib = (size_t)n * 6 * sizeof(uint32_t), ob = (size_t)n * 4 * sizeof(uint32_t);
+    int rc = ensure(ctx, ctx->b_in, ib); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_fout, ob); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_in.p, ctr_key, ib, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)ctx->b_in.p, n, (uint32_t*)ctx->b_fout.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_fout.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_sync(rt_ctx* ctx) {
     if (!ctx) return RT_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -766,6 +823,203 @@ int rt_device_cu_count(rt_ctx* ctx, int* out) {
     if (!ctx || !out) return RT_EINVAL;
     *out = ctx->cu_count;
     return RT_OK;
+}
+
+// ---- device memory for callers of the *_dev entry points ---------------------------------------------------------
+int rt_dev_alloc(rt_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return RT_EINVAL;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(ctx, RT_ENOMEM, "hipMalloc failed");
+    }
+    return RT_OK;
+}
+
+int rt_dev_free(rt_ctx* ctx, void* ptr) {
+    if (!ctx) return RT_EINVAL;
+    if (!ptr) return RT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // nothing enqueued may still use it
+    HIPCHK(ctx, hipFree(ptr));
+    return RT_OK;
+}
+
+int rt_memcpy_h2d(rt_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
+    if (!ctx) return RT_EINVAL;
+    if (bytes == 0) return RT_OK;
+    if (!dst_dev || !src) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_memcpy_d2h(rt_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+    if (!ctx) return RT_EINVAL;
+    if (bytes == 0) return RT_OK;
+    if (!dst || !src_dev) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// ---- the one collective of the path: RCCL, on the context's stream -----------------------------------------------
+// librccl.so.1 is loaded on first use (a one-GPU process never pays for it) and its entry points are taken from that
+// handle, so whichever RCCL the process already holds under that soname is the one used.
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+const Rccl* rccl_load(std::string& err) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return &g_rccl;
+    if (!g_rccl.err.empty()) { err = g_rccl.err; return nullptr; }
+    const char* names[] = {getenv("RT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    std::string tried;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        tried += std::string(n) + ": " + dlerror() + "; ";
+    }
+    if (!h) { g_rccl.err = err = "cannot load RCCL (" + tried + ")"; return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* f = dlsym(h, n); if (!f) { ok = false; tried += std::string("missing ") + n + "; "; } return f; };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(h); g_rccl.err = err = "RCCL library lacks entry points (" + tried + ")"; return nullptr; }
+    g_rccl.handle = h;
+    return &g_rccl;
+}
+
+#define NCCLCHK(ctx, R, call)                                                                         \
+    do {                                                                                              \
+        const ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) return fail(ctx, RT_ECOMM, std::string(#call) + ": " + (R)->GetErrorString(r_)); \
+    } while (0)
+}  // namespace
+
+int rt_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, RT_EINVAL, "id128 is NULL");
+    std::string err;
+    const Rccl* R = rccl_load(err);
+    if (!R) return fail(nullptr, RT_ECOMM, err);
+    static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "RT_COMM_ID_BYTES must be RCCL's unique-id size");
+    ncclUniqueId id;
+    NCCLCHK(nullptr, R, R->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx* ctx, int nranks, int rank, const void* id128) {
+    if (!ctx) return RT_EINVAL;
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, RT_EINVAL, "need id128, 0 <= rank < nranks");
+    if (ctx->comm) return fail(ctx, RT_EINVAL, "this context already has a communicator (rt_comm_destroy first)");
+    std::string err;
+    const Rccl* R = rccl_load(err);
+    if (!R) return fail(ctx, RT_ECOMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(ctx, R, R->CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->comm_rank = rank;
+    ctx->comm_nranks = nranks;
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx* ctx) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->comm) return RT_OK;
+    std::string err;
+    const Rccl* R = rccl_load(err);
+    if (!R) return fail(ctx, RT_ECOMM, err);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    const ncclComm_t c = ctx->comm;
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_nranks = 1;
+    NCCLCHK(ctx, R, R->CommDestroy(c));
+    return RT_OK;
+}
+
+int rt_comm_info(rt_ctx* ctx, int* rank, int* nranks) {
+    if (!ctx) return RT_EINVAL;
+    if (rank) *rank = ctx->comm_rank;
+    if (nranks) *nranks = ctx->comm_nranks;
+    return RT_OK;
+}
+
+int rt_comm_all_gather_f64_dev(rt_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->comm) return fail(ctx, RT_ENOTSET, "rt_comm_init has not been called on this context");
+    if (count < 0 || (count > 0 && (!send_dev || !recv_dev))) return fail(ctx, RT_EINVAL, "bad count or NULL argument");
+    if (count == 0) return RT_OK;
+    std::string err;
+    const Rccl* R = rccl_load(err);
+    if (!R) return fail(ctx, RT_ECOMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    NCCLCHK(ctx, R, R->AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+    return RT_OK;
+}
+
+int rt_comm_all_gather_f64(rt_ctx* ctx, const double* send, int64_t count, double* recv) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->comm) return fail(ctx, RT_ENOTSET, "rt_comm_init has not been called on this context");
+    if (count < 0 || (count > 0 && (!send || !recv))) return fail(ctx, RT_EINVAL, "bad count or NULL argument");
+    if (count == 0) return RT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t sb = (size_t)count * sizeof(double), rb = sb * (size_t)ctx->comm_nranks;
+    int rc = ensure(ctx, ctx->b_csend, sb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_crecv, rb); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_csend.p, send, sb, hipMemcpyHostToDevice, ctx->stream));
+    rc = rt_comm_all_gather_f64_dev(ctx, (const double*)ctx->b_csend.p, count, (double*)ctx->b_crecv.p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(recv, ctx->b_crecv.p, rb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_comm_all_reduce_max_f64(rt_ctx* ctx, double* values, int64_t count) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->comm) return fail(ctx, RT_ENOTSET, "rt_comm_init has not been called on this context");
+    if (count < 0 || (count > 0 && !values)) return fail(ctx, RT_EINVAL, "bad count or NULL argument");
+    if (count == 0) return RT_OK;
+    std::string err;
+    const Rccl* R = rccl_load(err);
+    if (!R) return fail(ctx, RT_ECOMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t sb = (size_t)count * sizeof(double);
+    int rc = ensure(ctx, ctx->b_csend, sb); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_csend.p, values, sb, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(ctx, R, R->AllReduce(ctx->b_csend.p, ctx->b_csend.p, (size_t)count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(values, ctx->b_csend.p, sb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_comm_barrier(rt_ctx* ctx) {
+    double one = 1.0;
+    return rt_comm_all_reduce_max_f64(ctx, &one, 1);
 }
 
 }  // extern "C"

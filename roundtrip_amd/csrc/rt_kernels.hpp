@@ -126,6 +126,9 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
 
     // zero the padded rows of the x0 image once: rows >= dx are never written again
     for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // orders the zero-fill against the first pass's put_x0 writes to the same words: a workgroup whose first pass is a
+    // leftover pass (p_main == 0, a pair range of only the last entry, p_main < grid) meets no other barrier before them
+    __syncthreads();
 
 #ifdef RT_STAMPS
     Stamps st;
@@ -229,13 +232,17 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             const bool live = lane < MS && valid;
             for (int k = 0; k < a.n_sd; ++k) {
                 double v = a.c_all[k] + (lw_t - se_t * a.inv_2sd2[k]);
-                if (!(live && v > -INFINITY && v < INFINITY)) v = -INFINITY;   // empty slot / non-finite score: weight 0
+                // a score of -inf (G overflowed to inf: exp(-inf) = 0) carries weight 0; NaN or +inf makes the
+                // reference's estimate of the point NaN (exp(v - max) at main_density_est.py:342, the product at :344),
+                // and the pair says so: (NaN, NaN), which is_finalize_kernel carries through
+                const unsigned long long bad = __builtin_amdgcn_ballot_w64(live && !(v < INFINITY));
+                if (!(live && v < INFINITY)) v = -INFINITY;                   // empty slot (or bad, flagged above)
                 if (!left) {
                     const double M = wave_max(v);
                     const double t = wave_sum((v > -INFINITY) ? exp(v - M) : 0.0);
                     if (lane == 0) {
                         double* dst = a.partial + 2 * ((n_u * a.E + j_u) * a.n_sd + k);
-                        dst[0] = M; dst[1] = t;
+                        dst[0] = bad ? (double)NAN : M; dst[1] = bad ? (double)NAN : t;
                     }
                 } else {
                     // lane i < q owns the i-th query point of the pass: slots i*rem .. i*rem + rem - 1
@@ -248,8 +255,10 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
                     }
                     const int64_t n_o = g_u * a.q + lane;
                     if (lane < a.q && n_o < a.N) {
+                        // rem <= MS/2 <= 32 and lane * rem + rem <= MS in packed mode: the shifts are in range
+                        const bool mine_bad = ((bad >> (lane * a.rem)) & ((1ull << a.rem) - 1ull)) != 0;
                         double* dst = a.partial + 2 * ((n_o * a.E + (a.E - 1)) * a.n_sd + k);
-                        dst[0] = M; dst[1] = t;
+                        dst[0] = mine_bad ? (double)NAN : M; dst[1] = mine_bad ? (double)NAN : t;
                     }
                 }
             }
@@ -276,13 +285,16 @@ __global__ __launch_bounds__(256) void is_finalize_kernel(const double* partial,
     for (int k = 0; k < n_sd; ++k) {
         const double* p = partial + 2 * (n * E * n_sd + k);
         double M = -INFINITY;
-        for (int64_t e = lane; e < E; e += 64) M = fmax(M, p[e * cs]);
+        for (int64_t e = lane; e < E; e += 64) M = fmax(M, p[e * cs]);   // fmax skips the NaN of a flagged pair
         M = wave_max(M);
         double t = 0.0;
         for (int64_t e = lane; e < E; e += 64)
-            if (p[e * cs] > -INFINITY) t += p[e * cs + 1] * exp(p[e * cs] - M);
+            if (!(p[e * cs] == -INFINITY)) t += p[e * cs + 1] * exp(p[e * cs] - M);   // a (NaN, NaN) pair makes t NaN
         t = wave_sum(t);
-        const double lp = (M > -INFINITY) ? M + log(t) - logS : -INFINITY;
+        // every weight 0: the reference's log branch forms (-inf) - (-inf) = NaN (main_density_est.py:342), its linear
+        // branch the mean of zeros (:345)
+        double lp = (M > -INFINITY) ? M + log(t) - logS : (log_flag ? (double)NAN : -INFINITY);
+        if (t != t) lp = (double)NAN;
         if (lane == 0) out[(int64_t)k * out_stride + n] = log_flag ? lp : exp(lp);
     }
 }
@@ -386,3 +398,12 @@ __global__ void draw_samples_kernel(SamplerArgs sa, const float* xhat, int64_t N
                 [&](int d, float v) { dst[d] = v; });
 }
 
+
+// The raw generator of the sampler on caller-chosen (counter, key) words: in[6t..6t+5] = c0 c1 c2 c3 k0 k1,
+// out[4t..4t+3] = philox4x32_10(...).  For the known-answer test against the published Random123 vectors.
+__global__ void philox_kernel(const uint32_t* in, int64_t n, uint32_t* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const U4 r = philox4x32_10(in[6 * t], in[6 * t + 1], in[6 * t + 2], in[6 * t + 3], in[6 * t + 4], in[6 * t + 5]);
+    out[4 * t] = r.x; out[4 * t + 1] = r.y; out[4 * t + 2] = r.z; out[4 * t + 3] = r.w;
+}

@@ -23,8 +23,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     return U4{c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ float u01(uint32_t x) {   // (0,1), 24 bits, never 0 or 1
-    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+// (k + 1/2) / 2^23 for the top 23 bits k: strictly inside (0, 1).  23 bits, not 24: k + 0.5 is exact in float32 only
+// for k < 2^23 — with 24 bits the top value rounds to 2^24, u = 1, log u = 0, and one normal in 2^24 is exactly 0 (a
+// chi2 of 0 for df = 1, an infinite sample, a NaN score: found in round 2 when NaN scores stopped being dropped).
+__device__ __forceinline__ float u01(uint32_t x) {
+    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "rt_is.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load()
     for name in declared:
@@ -40,7 +40,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "roundtrip_amd")
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, fn)
 

@@ -176,11 +176,11 @@ def test_rng_mode_matches_oracle_on_the_same_draws(engine, make_nets, dx, dy, df
     want = c_oracle.is_estimate_given_samples(og, y, xhat, xs.astype(np.float64), 0.1, 0.1, df, True,
                                               c_oracle.ORDER_KERNEL, 8)
     np.testing.assert_allclose(got, want, rtol=1e-12)
-    if df == float(int(df)):
-        # the oracle's restatement of the sampler agrees to a few float32 ulp (libm vs device logf/sincosf)
-        xo = c_oracle.draw_samples(xhat, 100, S, 0.1, df, 7)
-        close = np.isclose(xs, xo, rtol=2e-3, atol=1e-6)
-        assert close.mean() > 0.9999
+    # the oracle's restatement of the sampler agrees to a few float32 ulp (libm vs device logf/sincosf); on the gamma
+    # path (non-integer df) a borderline accept/reject may fall the other way once in a great while
+    xo = c_oracle.draw_samples(xhat, 100, S, 0.1, df, 7)
+    close = np.isclose(xs, xo, rtol=2e-3, atol=1e-6)
+    assert close.mean() > (0.9999 if df == float(int(df)) else 0.999)
 
 
 def test_sampler_statistics(engine, make_nets):
@@ -559,3 +559,170 @@ def test_random_shapes_against_the_oracle(engine, case_seed):
     alone = engine.is_estimate(y[k:k + 1], xhat[k:k + 1], S, c["sd"], c["scale"], log=c["log"], df=c["df"],
                                seed=c["seed"], y_index_base=c["base"] + k)
     assert np.array_equal(alone, got[k:k + 1]), c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 2
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dx,dy", [(2, 2), (20, 90)])
+@pytest.mark.parametrize("S", [7, 16, 32])
+def test_first_pass_is_a_leftover_pass(engine, make_nets, dx, dy, S):
+    """S <= 32: every pass of the launch is a packed leftover pass (p_main == 0), so a workgroup's first write to the x0
+    image follows its one-time zero-fill with nothing but the barrier after that fill in between; more query points
+    than CUs so that every workgroup runs.  Same for a pair range that holds only the last (leftover) entry."""
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    og = c_oracle.OracleMlp(gw, gb)
+    rng = np.random.RandomState(100 + S)
+    N = 3 * engine.cu_count() + 5
+    y = rng.standard_normal((N, dy)) * 0.3
+    xhat = (rng.standard_normal((N, dx)) * 0.3).astype(np.float32)
+    got = engine.is_estimate(y, xhat, S, 0.5, 0.1, seed=3)
+    xs = engine.draw_samples(xhat, S, 0.1, seed=3).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.1, 1.0, True, c_oracle.ORDER_KERNEL, nthreads=8)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    # given samples take the all-threads write path of the same phase
+    np.testing.assert_allclose(engine.is_estimate_given_samples(y, xhat, xs, 0.5, 0.1), want, rtol=1e-12, atol=1e-13)
+    # the last entry alone, at a sample count with full passes before it
+    S2 = 64 + S
+    E = engine.is_pair_count(S2)
+    full = engine.is_pairs(y, xhat, S2, [0.5], 0.1, 0, E, seed=3)
+    last = engine.is_pairs(y, xhat, S2, [0.5], 0.1, E - 1, E, seed=3)
+    assert np.array_equal(last[:, 0], full[:, E - 1])
+
+
+def _nan_generator(dx, dy):
+    """A generator that is finite near the origin and overflows far from it: two hidden layers of gain 1e19 each on
+    x_0 and on -x_0 (through the leaky-ReLU: 1e38 x_0 on the positive branch, -4e36 x_0 on the other), summed by the
+    output layer: finite for small x_0, +inf from x_0 ~ 3.4 on, inf + (-inf) = NaN from x_0 ~ 1e2 on."""
+    w0 = np.zeros((dx, 128), np.float32); w0[0, 0] = 1e19; w0[0, 1] = -1e19
+    w1 = np.zeros((128, 128), np.float32); w1[0, 0] = 1e19; w1[1, 1] = 1e19
+    w2 = np.zeros((128, dy), np.float32); w2[0, :] = 1.0; w2[1, :] = 1.0
+    return [w0, w1, w2], [np.zeros(128, np.float32), np.zeros(128, np.float32), np.zeros(dy, np.float32)]
+
+
+def test_non_finite_scores_follow_the_reference(engine):
+    """-inf scores (G overflowed to +-inf) weigh 0; a NaN score makes the point's estimate NaN, as the reference's
+    exp(v - max) / mean do (main_density_est.py:342,345); every score -inf gives NaN under log=True ((-inf) - (-inf))
+    and 0 under log=False.  The C oracle follows the reference literally, so it is the checker."""
+    ws, bs = _nan_generator(2, 2)
+    engine.set_mlp(G, ws, bs)
+    og = c_oracle.OracleMlp(ws, bs)
+    y = np.array([[0.1, -0.2], [0.0, 0.3], [0.2, 0.2], [1.0, 1.0]])
+    xhat = np.zeros((4, 2), np.float32)
+    S = 100
+    xs = np.zeros((4, S, 2))
+    xs[:, :, 0] = 1e-38                               # G = 0.96: finite scores
+    xs[:, :, 1] = np.linspace(-1, 1, S)
+    xs[1, 5, 0] = 10.0                                # the positive branch alone overflows: G = +inf, score -inf
+    xs[2, 70, 0] = 100.0                              # both branches overflow: G = inf + (-inf) = NaN
+    xs[3, :, 0] = 10.0                                # every sample -inf
+    out = og.forward(xs.reshape(-1, 2).astype(np.float32), order=c_oracle.ORDER_KERNEL).reshape(4, S, 2)
+    assert np.isfinite(out[0]).all() and np.isinf(out[1, 5]).all() and np.isnan(out[2, 70]).all()
+    for log in (True, False):
+        with np.errstate(all="ignore"):
+            want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.5, 1.0, log, c_oracle.ORDER_KERNEL)
+        got = engine.is_estimate_given_samples(y, xhat, xs, 0.5, 0.5, 1.0, log=log)
+        assert np.isfinite(got[:2]).all() and np.isnan(got[2]) and np.isnan(want[2]), (got, want)
+        np.testing.assert_allclose(got[:2], want[:2], rtol=1e-12)
+        if log:
+            assert np.isnan(got[3]) and np.isnan(want[3])
+        else:
+            assert got[3] == 0.0 and want[3] == 0.0
+    # the same through the packed leftover passes (S <= 32) and through the merge of pairs
+    got = engine.is_estimate_given_samples(y, xhat, np.ascontiguousarray(xs[:, 60:80]), 0.5, 0.5, 1.0)
+    assert np.isfinite(got[:2]).all() and np.isnan(got[2]) and np.isnan(got[3])
+
+
+@pytest.mark.parametrize("dx,dy,S,sd,scale", [(20, 90, 160000, 0.5, 0.1), (20, 90, 640000, 0.5, 0.1),
+                                              (8, 21, 40000, 0.1, 0.1), (5, 9, 40000, 0.1, 0.1)])
+def test_large_sample_counts_of_the_baseline_configs(engine, make_nets, dx, dy, S, sd, scale):
+    """BASELINE configs 3-5 at the sample counts that define them (YearPredictionMSD 20/90 at S = 160 000 / 640 000,
+    HEPMASS 8/21 and CASP 5/9 at 40 000): the sampler instantiation that shares a sample's Philox calls over four
+    threads sees sample indices up to 6.4e5 here.  Size-independent properties on all points — finite, exp(log) equals
+    the linear answer, a point evaluated alone is bit-identical, pair ranges merge to the estimate — and the oracle (kernel
+    order, 1e-12) on the GPU's own draws for one or two points."""
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    rng = np.random.RandomState(S % 1000 + dx)
+    N = 32 if S <= 160000 else 16
+    y = rng.standard_normal((N, dy)) * 0.3
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    base = 262144 - 5
+    lg = engine.is_estimate(y, xhat, S, sd, scale, y_index_base=base)
+    lin = engine.is_estimate(y, xhat, S, sd, scale, log=False, y_index_base=base)
+    assert np.all(np.isfinite(lg))
+    ok = lg > -600
+    np.testing.assert_allclose(np.log(lin[ok]), lg[ok], rtol=1e-12)
+    k = N - 3
+    alone = engine.is_estimate(y[k:k + 1], xhat[k:k + 1], S, sd, scale, y_index_base=base + k)
+    assert np.array_equal(alone, lg[k:k + 1])
+    # pair ranges of a few points, split at uneven places, merge to the same bits
+    E = engine.is_pair_count(S)
+    cuts = [0, E // 3, E // 3 + 1, E - 1, E]
+    sub = slice(0, 4)
+    parts = [engine.is_pairs(y[sub], xhat[sub], S, [sd], scale, lo, hi, y_index_base=base)
+             for lo, hi in zip(cuts[:-1], cuts[1:])]
+    merged = engine.is_merge_pairs(np.concatenate(parts, axis=1), S)[0]
+    assert np.array_equal(merged, lg[sub])
+    # oracle on the same draws
+    n_or = 2 if S <= 160000 else 1
+    og = c_oracle.OracleMlp(gw, gb)
+    xs = engine.draw_samples(xhat[:n_or], S, scale, y_index_base=base).astype(np.float64)
+    want = c_oracle.is_estimate_given_samples(og, y[:n_or], xhat[:n_or], xs, sd, scale, 1.0, True,
+                                              c_oracle.ORDER_KERNEL, nthreads=16)
+    np.testing.assert_allclose(lg[:n_or], want, rtol=1e-12, atol=1e-13)
+    # the oracle's own restatement of the sampler at the largest sample indices
+    tail = c_oracle.draw_samples(xhat[:1], base, S, scale, 1.0, 0)[0, -4096:]
+    assert np.mean(np.abs(tail - xs[0, -4096:]) <= 2e-3 * np.maximum(1.0, np.abs(tail))) >= 0.9999
+
+
+PHILOX_KAT = [   # Random123 kat_vectors, philox4x32 with 10 rounds: counter[4], key[2] -> output[4]
+    ([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def test_philox_known_answers_on_the_gpu(engine):
+    """The sampler's generator IS the published Philox4x32-10: the three Random123 known-answer vectors, and 10^5 random
+    (counter, key) rows against the C restatement (itself pinned to the same vectors in tests/test_oracle.py)."""
+    rows = np.array([c + k for c, k, _ in PHILOX_KAT], dtype=np.uint32)
+    got = engine.philox4x32_10(rows)
+    assert [list(map(int, r)) for r in got] == [o for _, _, o in PHILOX_KAT]
+    rnd = np.random.RandomState(9).randint(0, 2 ** 32, size=(100000, 6), dtype=np.uint64).astype(np.uint32)
+    got = engine.philox4x32_10(rnd)
+    want = np.stack([c_oracle.philox4x32_10(r[:4], r[4:]) for r in rnd[:2000]])
+    assert np.array_equal(got[:2000], want)
+    # the draws are that generator at counter = (sample, call, y lo, y hi), key = seed: first coordinate of sample i of
+    # query point n, decoded by hand from the raw words (df = 1, dx = 2: normals 0 = chi, 1 and 2 = coordinates)
+    engine.set_mlp(G, *[[np.zeros((2, 8), np.float32), np.zeros((8, 2), np.float32)],
+                        [np.zeros(8, np.float32), np.zeros(2, np.float32)]])
+    base, seed = (7 << 32) + 5, (3 << 32) + 11
+    xs = engine.draw_samples(np.zeros((2, 2), np.float32), 64, 1.0, 1.0, seed=seed, y_index_base=base)
+    ck = np.array([[i, 0, (base + n) & 0xffffffff, (base + n) >> 32, seed & 0xffffffff, seed >> 32]
+                   for n in range(2) for i in range(64)], dtype=np.uint32)
+    w = engine.philox4x32_10(ck).astype(np.float64)
+    u = ((w // 512) + 0.5) / 8388608.0
+    r0 = np.sqrt(-2 * np.log(u[:, 0])); g0, g1 = r0 * np.cos(2 * np.pi * u[:, 1]), r0 * np.sin(2 * np.pi * u[:, 1])
+    g2 = np.sqrt(-2 * np.log(u[:, 2])) * np.cos(2 * np.pi * u[:, 3])
+    np.testing.assert_allclose(xs.reshape(-1, 2)[:, 0], g1 / np.abs(g0), rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(xs.reshape(-1, 2)[:, 1], g2 / np.abs(g0), rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("df", [2.5, 7.3, 0.7, 40.0])
+def test_gamma_path_draws_match_the_restatement(engine, make_nets, df):
+    """Non-integer df (and integer df > 32): chi2 = 2 Gamma(df/2) by Marsaglia-Tsang — compared value by value with
+    the C restatement (oracle/is_oracle.c chi2_over_df_gamma), like the integer-df draws, not only by KS."""
+    gw, gb, _, _ = make_nets(5, 9)
+    engine.set_mlp(G, gw, gb)
+    xhat = (np.random.RandomState(2).standard_normal((3, 5)) * 0.3).astype(np.float32)
+    S = 20000
+    xs = engine.draw_samples(xhat, S, 0.5, df, seed=21, y_index_base=1 << 33)
+    xo = c_oracle.draw_samples(xhat, 1 << 33, S, 0.5, df, 21)
+    close = np.isclose(xs, xo, rtol=2e-3, atol=1e-5).all(axis=2)
+    assert close.mean() > 0.999, (df, close.mean())
+    u = (xs[0].astype(np.float64) - xhat[0]) / 0.5
+    assert stats.kstest(u[:, 3], stats.t(df).cdf).pvalue > 1e-3

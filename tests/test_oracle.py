@@ -257,3 +257,36 @@ def test_cf_golden_is_reproducible(name):
     np.testing.assert_allclose(is_ref.get_jacobian(g, f["xhat"]), f["jac_at_xhat"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(is_ref.estimate_py_with_CF(g, h, f["y"], sd_y=float(f["sd"]), log=True),
                                f["cf_log_est"], rtol=1e-6)
+
+
+def test_philox_known_answers():
+    """The restated generator is the published Philox4x32-10 (Salmon et al., SC'11): the known-answer vectors of the
+    Random123 distribution (kat_vectors: philox4x32, 10 rounds).  tests/test_gpu_parity.py asserts the same words on
+    the GPU."""
+    kat = [([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, out in kat:
+        assert list(map(int, c_oracle.philox4x32_10(ctr, key))) == out
+    # an independent statement of the round function in Python integers
+    def py_philox(c, k):
+        c, k = list(map(int, c)), list(map(int, k))
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return c
+    rnd = np.random.RandomState(5).randint(0, 2 ** 32, size=(200, 6), dtype=np.uint64)
+    for r in rnd:
+        assert list(map(int, c_oracle.philox4x32_10(r[:4], r[4:]))) == py_philox(r[:4], r[4:])
+
+
+@pytest.mark.parametrize("df", [0.7, 2.5, 7.3, 40.0])
+def test_oracle_gamma_path_statistics(df):
+    """Non-integer df: chi2 = 2 Gamma(df/2) (Marsaglia-Tsang), restated from rt_sampler.hpp: Student-t marginals and
+    the radial law of a bivariate t (r^2/2 ~ F(2, df))."""
+    xs = c_oracle.draw_samples(np.zeros((1, 2), np.float32), 17, 200000, 1.0, df, 1)[0].astype(np.float64)
+    for d in range(2):
+        assert stats.kstest(xs[:, d], stats.t(df).cdf).pvalue > 1e-3
+    assert stats.kstest((xs ** 2).sum(axis=1) / 2.0, stats.f(2, df).cdf).pvalue > 1e-3
