@@ -35,7 +35,7 @@ extern "C" {
 #define RT_ENOTSET       3   /* the MLP needed by the call has not been set */
 #define RT_EUNSUPPORTED  4   /* shape outside what the kernels handle */
 #define RT_ENOMEM        5
-#define RT_ETOOBIG       6   /* the call needs more than a fixed-size buffer holds */
+#define RT_ETOOBIG       6   /* the call needs more than a fixed-size buffer holds (rt_is_estimate_dev_noalloc) */
 #define RT_ECOMM         7   /* RCCL could not be loaded, or one of its calls failed */
 
 #define RT_MLP_G 0           /* generator  G: x (dx) -> y (dy)  : g_net, main_density_est.py:447 */
@@ -43,6 +43,7 @@ extern "C" {
 
 #define RT_MAX_LAYERS 24
 #define RT_MAX_SD 8          /* sd_y values one rt_is_estimate_multi call can score */
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)   /* the scratch array of rt_is_estimate_dev_noalloc, per GPU */
 #define RT_COMM_ID_BYTES 128 /* size of the rendezvous token of rt_comm_unique_id / rt_comm_init */
 
 typedef struct rt_ctx rt_ctx;
@@ -150,6 +151,20 @@ int rt_philox4x32_10(rt_ctx* ctx, const uint32_t* ctr_key, int64_t n, uint32_t* 
 int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
                        int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
                        uint64_t seed, int log_flag, double* out_dev);
+
+/* rt_is_estimate_dev for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels, bit-identical results; it calls no
+ * hipMalloc / hipFree / hipEventCreate (so rt_get_counters does not see its launches).  The one buffer the estimate
+ * needs beyond its inputs and outputs — the per-pass (max v, sum exp(v - max)) pairs, 16 bytes per 64 samples (32 at
+ * hidden width 1024) of every query point — lives in a file-scope __device__ array of RT_NOALLOC_SCRATCH_BYTES
+ * (32 MiB) that every GPU the library runs on holds until the process ends.  A call whose pairs do not fit,
+ *     N * ceil(S / 64) * 16  >  RT_NOALLOC_SCRATCH_BYTES        (e.g. N > 13 357 at S = 10 000)
+ * is refused with RT_ETOOBIG and a message that names the largest N for this S; split it into several calls.  Every
+ * pair a call reads it has written first, so the array needs no clearing between calls; all contexts on one GPU share
+ * it, so calls that overlap on one GPU (two contexts, two threads) race — serialise them. */
+int rt_is_estimate_dev_noalloc(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
+                               int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
+                               uint64_t seed, int log_flag, double* out_dev);
 
 /* --- Splitting one query point's SAMPLES over callers (second axis: fewer query points than GPUs) ------
  * The fused kernel reduces every pass (64 samples; 32 at hidden width 1024) of a query point to a pair

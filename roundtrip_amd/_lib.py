@@ -19,7 +19,7 @@ SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_mlp", "rt_mlp_forward", "rt_mlp_jacobian", "rt_encode",
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
-    "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs",
+    "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs", "rt_is_estimate_dev_noalloc",
     "rt_philox4x32_10",
     "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
@@ -28,6 +28,7 @@ SYMBOLS = (
 
 RT_ETOOBIG = 6
 RT_ECOMM = 7
+RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 RT_COMM_ID_BYTES = 128
 
 
@@ -78,6 +79,7 @@ def load():
     lib.rt_is_pair_count.argtypes = [vp, i64, C.POINTER(i64)]
     lib.rt_is_pairs.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, dbl, dbl, C.c_uint64, i64, i64, vp]
     lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
+    lib.rt_is_estimate_dev_noalloc.argtypes = lib.rt_is_estimate_dev.argtypes
     lib.rt_philox4x32_10.argtypes = [vp, vp, i64, vp]
     lib.rt_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.rt_dev_free.argtypes = [vp, vp]
@@ -269,6 +271,13 @@ class Engine(object):
         self._chk(self._lib.rt_is_estimate_dev(self._h, y_ptr, xhat_ptr, int(N), int(y_index_base),
                                                int(sample_size), float(sd_y), float(scale), float(df),
                                                int(seed), int(bool(log)), out_ptr))
+
+    def is_estimate_dev_noalloc(self, y_ptr, xhat_ptr, N, sample_size, sd_y, scale, out_ptr, df=1.0, seed=0,
+                                log=True, y_index_base=0):
+        """rt_is_estimate_dev for callers that cannot allocate (rt_is.h): pairs go to the per-GPU scratch array."""
+        self._chk(self._lib.rt_is_estimate_dev_noalloc(self._h, y_ptr, xhat_ptr, int(N), int(y_index_base),
+                                                       int(sample_size), float(sd_y), float(scale), float(df),
+                                                       int(seed), int(bool(log)), out_ptr))
 
     # ---- device memory (rt_dev_alloc & co.): what callers of the *_dev entry points keep their arrays in ----
     def dev_alloc(self, nbytes):

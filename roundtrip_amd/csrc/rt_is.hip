@@ -44,6 +44,17 @@ namespace {
 #include "rt_kernels.hpp"
 
 // ----------------------------------------------------------------------------------------------
+// Scratch of the no-allocation entry point (rt_is_estimate_dev_noalloc): the fused kernel's per-pass (max, sum) pairs go
+// here instead of into a hipMalloc'ed buffer.  One copy per GPU, held until the process ends.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress (rt_ctx_create, once per device); everything else uses the device
+// address kept in g_scratch_ptr / rt_ctx::scratch.
+// ----------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on HIP device i (nullptr: not looked up yet)
+std::mutex g_scratch_mu;
+
+// ----------------------------------------------------------------------------------------------
 // Host side
 // ----------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -75,6 +86,7 @@ struct rt_ctx {
     size_t events_used = 0;
     double ms_harvested = 0.0;              // durations already folded in by harvest_events()
     uint64_t launches_harvested = 0;
+    void* scratch = nullptr;                // this device's copy of the `scratch` array (see above)
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
@@ -345,8 +357,17 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
         if (!(sd_ys[k] > 0.0) || !isfinite(sd_ys[k])) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
     if (N == 0) return RT_OK;
     const int dx = G.args.in_dim, dy = G.args.out_dim;
-    if (fixed && (size_t)N > fixed->cap / is_partial_bytes(1, S, G.nst, n_sd))
-        return fail(ctx, RT_ETOOBIG, "the pairs of this call exceed the fixed pair buffer");
+    if (fixed) {
+        const size_t one = is_partial_bytes(1, S, G.nst, n_sd);
+        if ((size_t)N > fixed->cap / one) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "rt_is_estimate_dev_noalloc: N = %lld query points x %lld (max, sum) pairs x 16 B exceed "
+                     "the %u-byte scratch array (RT_NOALLOC_SCRATCH_BYTES): at this sample_size at most %lld query points "
+                     "per call", (long long)N, (long long)(one / 16), (unsigned)RT_NOALLOC_SCRATCH_BYTES,
+                     (long long)(fixed->cap / one));
+            return fail(ctx, RT_ETOOBIG, msg);
+        }
+    }
     int64_t per = ctx->max_launch_evals / S;
     {   // ... and to 1 GiB of per-pass partial results (16 B per pass and sd value; only matters for tiny S)
         const int64_t per_mem = (int64_t)((1ull << 30) / is_partial_bytes(1, S, G.nst, n_sd));
@@ -442,6 +463,21 @@ int rt_ctx_create(int device, rt_ctx** out) {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
     ctx->lds_allowed.reserve(64);    // so that no launch path grows it (rt_is_estimate_dev_noalloc allocates nothing)
+    if (device < MAX_DEVICES) {
+        // the device address of this GPU's copy of `scratch`, looked up once per device with that device current
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            void* ptr = nullptr;
+            e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) {
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return fail(nullptr, RT_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+            }
+            g_scratch_ptr[device] = ptr;
+        }
+        ctx->scratch = g_scratch_ptr[device];
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -652,6 +688,17 @@ int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, 
     if (N > 0 && (!y_dev || !xhat_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev);
+}
+
+int rt_is_estimate_dev_noalloc(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
+                               int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
+                               uint64_t seed, int log_flag, double* out_dev) {
+    if (!ctx) return RT_EINVAL;
+    if (N > 0 && (!y_dev || !xhat_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
+    if (!ctx->scratch) return fail(ctx, RT_EUNSUPPORTED, "no scratch array on this device (HIP device index >= 64)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const PairBuf pb{(double*)ctx->scratch, (size_t)RT_NOALLOC_SCRATCH_BYTES, false};
+    return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev, &pb);
 }
 
 int rt_is_pair_count(rt_ctx* ctx, int64_t S, int64_t* E) {
