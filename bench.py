@@ -4,20 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no launcher environment (no RANK), this process starts N fresh rank processes itself — before it
+touches the GPU — and relays rank 0's JSON line and the exit code.  Under a launcher it is one rank.
+
 A step = one pass of the hot path over one batch of synthetic query points already resident in HBM:
 H-forward (proposal centres) -> fused sampler + G forward + scoring + log-sum-exp kernel -> finalize
-(-> one RCCL all-gather of the results when N > 1).  Workload = BASELINE.json configs[1]: the
-eight_octagon_gmm 100x100 evaluation grid on [-5,5]^2 (/root/reference/evaluate.py:237), dx = dy = 2,
+(-> one RCCL all-gather of the results when N > 1, on the same stream).  Default workload = BASELINE.json configs[1]:
+the eight_octagon_gmm 100x100 evaluation grid on [-5,5]^2 (/root/reference/evaluate.py:237), dx = dy = 2,
 S = 10000 (evaluate.py:225), sd_y = 0.1, scale = 0.5, log=False, G = [2, 512x10, 2], H = [2, 256x10, 2],
 Glorot-uniform weights from RandomState(1234).  With N GPUs the grid is tiled N times
-and sharded contiguously (weak scaling: 10000 query points per GPU).
+and sharded contiguously (weak scaling: 10000 query points per GPU).  --workload selects BASELINE.md §4's other rows
+(config 3: AReM 3/6, S = 40000; config 5: YearPredictionMSD 20/90, strong 262144 points / weak 131072 per GPU).
 
-Prints ONE JSON line on rank 0.  The cpu_baseline leg (rank 0, N = 1 only) times the C restatement
-oracle/is_oracle.c — a port, not TensorFlow — on a bounded sample of the same workload.
+No torch: device buffers, the collective (RCCL) and the timing fences all go through librt_is.so's C ABI.
+
+Prints ONE JSON line on rank 0.  The cpu_baseline leg (rank 0, N = 1 only) times the CPU restatements — ports, not
+TensorFlow — on bounded samples of the same workload: oracle/is_oracle.c (C + OpenMP) and oracle/is_ref.py (numpy/scipy,
+the reference's per-point structure, main_density_est.py:324-335).
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X: 256 CU x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
+
+# name -> (dx, dy, sd_y, scale, default S, log, query points per GPU (weak) or in total (strong), scaling, description)
+WORKLOADS = {
+    "grid": (2, 2, 0.1, 0.5, 10000, False, None, "weak",
+             "eight_octagon_gmm 2D evaluation grid %(g)dx%(g)d on [-5,5]^2 per GPU (evaluate.py shape)"),
+    "arem": (3, 6, 0.1, 0.1, 40000, True, 125000, "weak",
+             "UCI AReM 3/6, y ~ N(0,I) RandomState(42), 1M query points over 8 GPUs = 125000 per GPU (BASELINE config 3)"),
+    "casp": (5, 9, 0.1, 0.1, 40000, True, 125000, "weak",
+             "UCI CASP 5/9, y ~ N(0,I) RandomState(42), 125000 query points per GPU (BASELINE config 3)"),
+    "ypmsd-weak": (20, 90, 0.5, 0.1, 40000, True, 131072, "weak",
+                   "UCI YearPredictionMSD 20/90, y ~ N(0,I) RandomState(42), 131072 query points per GPU (BASELINE config 5)"),
+    "ypmsd-strong": (20, 90, 0.5, 0.1, 40000, True, 262144, "strong",
+                     "UCI YearPredictionMSD 20/90, y ~ N(0,I) RandomState(42), 262144 query points in total (BASELINE config 5)"),
+}
 
 
 def build_nets(dx, dy):
@@ -45,9 +69,9 @@ def grid_points(n=100, lo=-5.0, hi=5.0):
     return np.vstack((v1.ravel(), v2.ravel())).T
 
 
-def cpu_baseline(g, h, y, S, sd, scale, n_points, eng):
-    """Times the CPU restatement on n_points query points x S samples (same draws the GPU uses)."""
-    from oracle import c_oracle
+def cpu_baseline(g, h, y, S, sd, scale, log, n_points, n_points_numpy, eng):
+    """Times the CPU restatements on bounded samples of the workload (same draws the GPU uses)."""
+    from oracle import c_oracle, is_ref
     from roundtrip_amd import _lib
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     ys = np.ascontiguousarray(y[:: max(1, len(y) // n_points)][:n_points])
@@ -55,18 +79,40 @@ def cpu_baseline(g, h, y, S, sd, scale, n_points, eng):
     xs = eng.draw_samples(xhat, S, scale, df=1.0, seed=0).astype(np.float64)
     og = c_oracle.OracleMlp(g.weights, g.biases, g.alpha)
     t0 = time.perf_counter()
-    out = c_oracle.is_estimate_given_samples(og, ys, xhat, xs, sd, scale, 1.0, False, c_oracle.ORDER_NATURAL,
+    out = c_oracle.is_estimate_given_samples(og, ys, xhat, xs, sd, scale, 1.0, log, c_oracle.ORDER_NATURAL,
                                              nthreads=threads)
     dt = time.perf_counter() - t0
-    gpu = eng.is_estimate_given_samples(ys, xhat, xs, sd, scale, 1.0, log=False)
+    gpu = eng.is_estimate_given_samples(ys, xhat, xs, sd, scale, 1.0, log=log)
     ok = bool(np.allclose(gpu, out, rtol=1e-4, atol=1e-300))
-    return {"value": len(ys) * S / dt, "unit": "sample-evals/s", "cores": threads, "kind": "port",
-            "sample": "%d grid points x S=%d through oracle/is_oracle.c (C + OpenMP restatement, not TensorFlow); "
-                      "matches GPU on this sample: %s" % (len(ys), S, ok),
-            "seconds": dt}
+    res = {"value": len(ys) * S / dt, "unit": "sample-evals/s", "cores": threads, "kind": "port",
+           "sample": "%d query points x S=%d through oracle/is_oracle.c (C + OpenMP restatement, not TensorFlow); "
+                     "matches GPU on this sample: %s" % (len(ys), S, ok),
+           "seconds": dt}
+    if n_points_numpy > 0:
+        # the reference's own structure (main_density_est.py:324-335): one query point after another, G in 1024-row
+        # sub-batches (predict_y), scipy.stats.t.logpdf, Python max(); numpy/scipy arithmetic, Python-level single thread
+        # (the reference's pool is GIL-bound), BLAS threads as the box sets them
+        try:
+            from threadpoolctl import threadpool_info
+            blas = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+        except Exception:
+            blas = None
+        n2 = min(n_points_numpy, len(ys))
+        gn, hn = is_ref.DenseNet(g.weights, g.biases, g.alpha), is_ref.DenseNet(h.weights, h.biases, h.alpha)
+        t0 = time.perf_counter()
+        out2 = is_ref.estimate_py_with_IS(gn, hn, ys[:n2], sd_y=sd, scale=scale, sample_size=S, bs=1024, df=1, log=log,
+                                          x_samples=xs[:n2])
+        dt2 = time.perf_counter() - t0
+        ok2 = bool(np.allclose(gpu[:n2], out2, rtol=1e-4, atol=1e-300))
+        res["numpy_restatement"] = {
+            "value": n2 * S / dt2, "unit": "sample-evals/s", "cores": blas, "kind": "port", "seconds": dt2,
+            "sample": "%d query points x S=%d through oracle/is_ref.py (numpy/scipy statement-by-statement restatement of "
+                      "main_density_est.py:266-348: per-point loop, 1024-row G sub-batches, scipy t.logpdf; one Python "
+                      "thread, %s BLAS threads; not TensorFlow); matches GPU on this sample: %s" % (n2, S, blas, ok2)}
+    return res
 
 
-def recorded_traffic(grid, S, dx, dy):
+def recorded_traffic(key):
     """HBM-side bytes per launch of the fused kernel for THIS workload from the committed PMC passes
     (profiles/r*_pmc_v*.json, written by scripts/pmc.sh + scripts/pmc_profile.py).  The fallback of live_traffic()."""
     import glob
@@ -77,23 +123,21 @@ def recorded_traffic(grid, S, dx, dy):
         except (OSError, ValueError):
             continue
         k = d.get("bench_key", {})
-        if (k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy")) == (grid, S, dx, dy) \
-                and "traffic_bytes_per_launch" in d:
+        if (k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy")) == key and "traffic_bytes_per_launch" in d:
             best = (d["traffic_bytes_per_launch"], "PMC passes recorded in profiles/%s" % os.path.basename(f))
     return best
 
 
-def _pmc_pass(counter, grid, S, timeout_s=150):
+def _pmc_pass(counter, child_args, timeout_s=150):
     """One rocprofv3 --pmc pass over a child run of this script (one launch of the same workload); returns the counter's
     value for the last dispatch of the fused kernel, summed over its rows, or None."""
-    import csv, glob, shutil, signal, subprocess, tempfile
+    import csv, glob, shutil, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     out = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
-    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-           "--grid", str(grid), "--sample-size", str(S), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-           "--no-live-traffic"]
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + \
+        child_args + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-live-traffic"]
     try:
         proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                 stderr=subprocess.DEVNULL, start_new_session=True)
@@ -118,7 +162,7 @@ def _pmc_pass(counter, grid, S, timeout_s=150):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def live_traffic(grid, S):
+def live_traffic(child_args):
     """HBM-side bytes of ONE launch of the fused kernel on this workload, measured now: FETCH_SIZE and WRITE_SIZE from two
     separate rocprofv3 --pmc passes over child runs of this script, corrected as MI355X_MICROARCH.md (HBM section)
     prescribes: both are in KiB, and on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B/lane loads — the weight
@@ -126,14 +170,50 @@ def live_traffic(grid, S):
     profiled (a profiler inside a profiled run)."""
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None
-    fetch = _pmc_pass("FETCH_SIZE", grid, S)
+    fetch = _pmc_pass("FETCH_SIZE", child_args)
     if fetch is None:
         return None
-    write = _pmc_pass("WRITE_SIZE", grid, S)
+    write = _pmc_pass("WRITE_SIZE", child_args)
     if write is None:
         return None
     return (2.0 * fetch * 1024.0 + write * 1024.0, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate child "
             "runs of one launch each), KiB units, FETCH doubled (gfx950 wide loads)")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """--gpus N > 1 without a launcher: N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, like torch.distributed.run sets them), started before this process has made any GPU call.  This parent
+    only relays: the ranks inherit stdout/stderr (rank 0 prints the JSON line), and the exit code is the first failure's.
+    A rank that fails takes the others down (by their exact PIDs)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_COMM_RUN_ID="bench-%d" % os.getpid())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for o in sorted(live):
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -141,99 +221,137 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sample-size", type=int, default=10000)
-    ap.add_argument("--grid", type=int, default=100, help="grid side; query points per GPU = grid^2")
+    ap.add_argument("--workload", default="grid", choices=sorted(WORKLOADS),
+                    help="grid = BASELINE config 2 (the default, what the metric is quoted on at N = 1); the others are "
+                         "BASELINE.md §4 rows 3 and 5 at full size")
+    ap.add_argument("--sample-size", type=int, default=None, help="S (default: the workload's)")
+    ap.add_argument("--grid", type=int, default=100, help="grid workload: grid side; query points per GPU = grid^2")
+    ap.add_argument("--points", type=int, default=None,
+                    help="other workloads: query points per GPU (weak) or in total (strong) instead of the BASELINE size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the PMC passes recorded under profiles/ instead of two live rocprofv3 passes")
     ap.add_argument("--cpu-points", type=int, default=160,
                     help="query points of the cpu_baseline sample (160 x S=10000 is about 13 s on 16 host cores)")
+    ap.add_argument("--cpu-points-numpy", type=int, default=64,
+                    help="query points of the numpy-restatement leg of cpu_baseline (64 x S=10000 is about 5 s on 16 BLAS threads)")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never used by the driver):
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend; gloo gathers through host tensors (rehearsal only)")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="rccl (= nccl): the gather runs on RCCL through librt_is.so; gloo: through torch.distributed on "
+                         "host tensors (rehearsal only: RCCL refuses two ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))          # nothing above has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
-    import torch
-    dev_index = 0 if args.share_gpu else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    host_gather = args.backend == "gloo"
-    if world > 1:
-        import torch.distributed as dist
-        if host_gather:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
     from roundtrip_amd import _lib, dist as rdist
-    dx = dy = 2
-    S, sd, scale = args.sample_size, 0.1, 0.5
+    dev_index = 0 if args.share_gpu else local_rank
+    use_gloo = args.backend == "gloo"
+    tdist = None
+    if world > 1 and use_gloo:
+        import torch
+        import torch.distributed as tdist
+        tdist.init_process_group("gloo")
+
+    dx, dy, sd, scale, S_default, log, n_points, scaling, desc = WORKLOADS[args.workload]
+    S = args.sample_size or S_default
     g, h = build_nets(dx, dy)
     eng = _lib.Engine(dev_index)
     eng.set_mlp(_lib.RT_MLP_G, g.weights, g.biases, g.alpha)
     eng.set_mlp(_lib.RT_MLP_H, h.weights, h.biases, h.alpha)
+    if world > 1 and not use_gloo:
+        rdist.init(eng)                            # RCCL communicator on the engine's device and stream
 
-    per_gpu = args.grid * args.grid
-    y_all = np.tile(grid_points(args.grid), (world, 1))          # global batch, weak scaling
-    n_total = y_all.shape[0]
-    lo, hi = rdist.shard_bounds(n_total, world, rank)
-    y_dev = torch.from_numpy(np.ascontiguousarray(y_all[lo:hi])).to(dev)          # float64, resident
-    y32_dev = y_dev.to(torch.float32)                                             # H's float32 feed
-    xhat_dev = torch.empty((hi - lo, dx), dtype=torch.float32, device=dev)
-    out_dev = torch.zeros(per_gpu, dtype=torch.float64, device=dev)
-    gathered = (torch.empty(per_gpu * world, dtype=torch.float64, device="cpu" if host_gather else dev)
-                if world > 1 else None)
-    torch.cuda.synchronize()
+    if args.workload == "grid":
+        per_gpu = args.grid * args.grid
+        n_total = per_gpu * world
+        tile = grid_points(args.grid)
+        lo, hi = rdist.shard_bounds(n_total, world, rank)
+        y_mine = np.ascontiguousarray(np.tile(tile, (world, 1))[lo:hi])
+        desc = desc % {"g": args.grid}
+    else:
+        n_points = args.points or n_points
+        n_total = n_points * world if scaling == "weak" else n_points
+        lo, hi = rdist.shard_bounds(n_total, world, rank)
+        # rows [lo, hi) of the one global stream RandomState(42).standard_normal((n_total, dy)), float32 values
+        rs = np.random.RandomState(42)
+        skip = lo * dy
+        while skip > 0:
+            k = min(skip, 1 << 24)
+            rs.standard_normal(k)
+            skip -= k
+        y_mine = rs.standard_normal((hi - lo, dy)).astype(np.float32).astype(np.float64)
+    per = -(-n_total // world)
+    n_mine = hi - lo
+    y_dev = eng.to_device(y_mine)                                              # float64, resident
+    y32_dev = eng.to_device(y_mine.astype(np.float32))                         # H's float32 feed
+    xhat_dev = eng.dev_alloc(max(1, n_mine) * dx * 4)
+    out_dev = eng.to_device(np.zeros(per, dtype=np.float64))
+    gathered_dev = eng.dev_alloc(per * world * 8) if world > 1 and not use_gloo else None
+    gathered_host = None
 
     def step():
-        eng.mlp_forward_dev(_lib.RT_MLP_H, y32_dev.data_ptr(), hi - lo, xhat_dev.data_ptr())
-        eng.is_estimate_dev(y_dev.data_ptr(), xhat_dev.data_ptr(), hi - lo, S, sd, scale, out_dev.data_ptr(),
-                            df=1.0, seed=0, log=False, y_index_base=lo)
+        nonlocal gathered_host
+        eng.mlp_forward_dev(_lib.RT_MLP_H, y32_dev, n_mine, xhat_dev)
+        eng.is_estimate_dev(y_dev, xhat_dev, n_mine, S, sd, scale, out_dev, df=1.0, seed=0, log=log, y_index_base=lo)
         if world > 1:
-            eng.sync()   # results are produced on the engine's stream; the gather runs on torch's
-            dist.all_gather_into_tensor(gathered, out_dev.cpu() if host_gather else out_dev)
+            if use_gloo:
+                loc = torch.from_numpy(eng.from_device(out_dev, (per,), np.float64))       # waits for the stream
+                gathered_host = torch.empty(per * world, dtype=torch.float64)
+                tdist.all_gather_into_tensor(gathered_host, loc)
+            else:
+                eng.comm_all_gather_dev(out_dev, per, gathered_dev)                        # same stream, no host hop
 
-    def fence():
-        eng.sync()
-        torch.cuda.synchronize()
+    def barrier():
         if world > 1:
-            dist.barrier()
+            tdist.barrier() if use_gloo else eng.comm_barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        if use_gloo:
+            t = torch.tensor([x], dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            return float(t.item())
+        return float(eng.comm_all_reduce_max([x])[0])
 
     for _ in range(args.warmup):
         step()
-    fence()
+    eng.sync()          # everything this process puts on the GPU runs on the engine's stream
+    barrier()
     eng.reset_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     eng.sync()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    barrier()
+    elapsed = max_over_ranks(elapsed)
     ctr = eng.counters()
 
     if rank == 0:
         evals = float(n_total) * S * args.steps
-        res = (gathered if world > 1 else out_dev).cpu().numpy()
+        if world == 1:
+            res = eng.from_device(out_dev, (per,), np.float64)[:n_total]
+        elif use_gloo:
+            res = gathered_host.numpy()[:n_total]
+        else:
+            res = eng.from_device(gathered_dev, (per * world,), np.float64)[:n_total]
         achieved = ctr["flops"] / (ctr["kernel_ms"] * 1e-3) / 1e12 if ctr["kernel_ms"] > 0 else 0.0
         traffic = None
+        child_args = ["--workload", args.workload, "--grid", str(args.grid), "--sample-size", str(S)] + \
+            (["--points", str(args.points)] if args.points else [])
         if world == 1 and not args.no_live_traffic:
-            traffic = live_traffic(args.grid, S)
-        if traffic is None:
-            traffic = recorded_traffic(args.grid, S, dx, dy)
+            traffic = live_traffic(child_args)
+        if traffic is None and args.workload == "grid":
+            traffic = recorded_traffic((args.grid, S, dx, dy))
+        share = dx + 1 > 4
         line = {
             "metric": "IS sample-evals/sec (N_y x S through G)",
             "value": evals / elapsed,
@@ -243,30 +361,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "eight_octagon_gmm 2D evaluation grid %dx%d on [-5,5]^2 per GPU (evaluate.py shape), "
-                                   "dx=2 dy=2, S=%d, sd_y=0.1 scale=0.5 df=1 log=False, G=[2,512x10,2] H=[2,256x10,2] "
-                                   "Glorot RandomState(1234)" % (args.grid, args.grid, S),
-                       "query_points_total": int(n_total), "sample_size": S, "parallelism": "y-shard x%d" % world},
+            "config": {"workload": "%s, dx=%d dy=%d, S=%d, sd_y=%g scale=%g df=1 log=%s, G=[%d,512x10,%d] H=[%d,256x10,%d] "
+                                   "Glorot RandomState(1234)" % (desc, dx, dy, S, sd, scale, log, dx, dy, dy, dx),
+                       "query_points_total": int(n_total), "sample_size": S, "parallelism": "y-shard x%d" % world,
+                       "collective": None if world == 1 else ("gloo (rehearsal)" if use_gloo else "rccl all-gather")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic[0] if traffic else None, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "is_fused_kernel<512, 2, false, false>",
+                         "kernel": "is_fused_kernel<512, 2, false, %s>" % ("true" if share else "false"),
                          "kernel_ms_avg": ctr["kernel_ms"] / max(1, ctr["launches"]),
                          "launches": ctr["launches"],
                          "flops_per_sample_eval": ctr["flops"] / max(1, ctr["sample_evals"])},
-            "result_check": {"finite": bool(np.all(np.isfinite(res))), "mean_density": float(res.mean())},
+            "result_check": {"finite": bool(np.all(np.isfinite(res))), "mean": float(res.mean())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(g, h, y_all, S, sd, scale, args.cpu_points, eng)
+            y_host = y_mine
+            line["cpu_baseline"] = cpu_baseline(g, h, y_host, S, sd, scale, log, args.cpu_points, args.cpu_points_numpy, eng)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()
+    if world > 1 and not use_gloo:
+        rdist.shutdown()
+    if tdist is not None:
+        tdist.destroy_process_group()
+    for p in (y_dev, y32_dev, xhat_dev, out_dev, gathered_dev):
+        eng.dev_free(p)
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -5,9 +5,25 @@ final np.array(...) at :342), so the path shards with no data-path collective: r
 contiguous block of query points and one all-gather assembles the N float64 results.  The proposal
 sampler is keyed by the GLOBAL query index, so the result is bit-identical for any rank count.
 
-torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+The gather runs on RCCL behind the C ABI (rt_comm_* in include/rt_is.h, on the engine's own stream): `init(engine)`
+makes the communicator from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT — what
+`python -m torch.distributed.run` and `bench.py --gpus N` export), exchanging RCCL's 128-byte id over a small TCP
+rendezvous of its own.  Nothing here imports torch.  A caller that ALREADY runs a torch.distributed process group
+(its own application, or the gloo-on-CPU tests of this repo) and has not called `init` gets its group used instead.
 """
+import hashlib
+import os
+import socket
+import struct
+import sys
+import time
+
 import numpy as np
+
+_MAGIC = b"RTID"
+_PORT_SPAN = 16          # candidate rendezvous ports: MASTER_PORT + 1 .. MASTER_PORT + _PORT_SPAN
+_native = None           # (engine, rank, world_size) once init() has run
+_epoch = 0               # rendezvous count of this process: keeps a second init() from meeting a stale first one
 
 
 def shard_bounds(n, world_size, rank):
@@ -19,45 +35,177 @@ def shard_bounds(n, world_size, rank):
     return lo, hi
 
 
+# ---- rendezvous: rank 0 hands RCCL's unique id to the other ranks ------------------------------------------------
+def _token(addr, port, world_size, epoch):
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "/" + os.environ.get("RT_COMM_RUN_ID", "")
+    return hashlib.sha256(("%s:%d:%d:%d:%s" % (addr, port, world_size, epoch, run)).encode()).digest()[:16]
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous connection")
+        buf += chunk
+    return buf
+
+
+def exchange_id(make_id, rank, world_size, addr, port, timeout=300.0, epoch=0):
+    """Returns rank 0's `make_id()` bytes on every rank.  Rank 0 listens on the first free port of
+    [port + 1, port + _PORT_SPAN] (MASTER_PORT itself belongs to the launcher's store) and serves every peer that
+    presents the run's token; peers walk the same candidates until one answers with the magic — a foreign server on a
+    candidate port is skipped, not trusted."""
+    if world_size == 1:
+        return make_id()
+    tok = _token(addr, port, world_size, epoch)
+    deadline = time.time() + timeout
+    cands = [port + 1 + i for i in range(_PORT_SPAN)]
+    if rank == 0:
+        srv = None
+        for p in cands:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, p))
+                s.listen(world_size + 8)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise RuntimeError("rendezvous: no free port in %d..%d on %s" % (cands[0], cands[-1], addr))
+        uid = make_id()
+        served = set()
+        try:
+            while len(served) < world_size - 1:
+                left = deadline - time.time()
+                if left <= 0:
+                    raise TimeoutError("rendezvous: %d of %d peers arrived within %.0f s"
+                                       % (len(served), world_size - 1, timeout))
+                srv.settimeout(min(left, 5.0))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        hello = _recv_exact(conn, 20)
+                        peer = struct.unpack("<i", hello[16:])[0]
+                        if hello[:16] != tok or not 0 < peer < world_size:
+                            continue                                    # not one of ours
+                        conn.sendall(_MAGIC + uid)
+                        _recv_exact(conn, 1)                            # the peer has it
+                        served.add(peer)
+                    except (OSError, ConnectionError):
+                        continue
+        finally:
+            srv.close()
+        return uid
+    last = None
+    while time.time() < deadline:
+        for p in cands:
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(tok + struct.pack("<i", rank))
+                    head = _recv_exact(conn, 4)
+                    if head != _MAGIC:
+                        continue
+                    uid = _recv_exact(conn, 128)
+                    conn.sendall(b"k")
+                    return uid
+            except (OSError, ConnectionError) as e:
+                last = e
+        time.sleep(0.2)
+    raise TimeoutError("rendezvous: rank 0 did not answer on %s:%d..%d within %.0f s (%r)"
+                       % (addr, cands[0], cands[-1], timeout, last))
+
+
+def init(engine, rank=None, world_size=None, addr=None, port=None, timeout=300.0):
+    """Collective over all ranks: makes the RCCL communicator of `engine` (one rank per GPU).  Arguments default to
+    the launcher's environment.  Afterwards world() and the gathers below use it."""
+    global _native, _epoch
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) if port is None else int(port)
+    if not 0 <= rank < world_size:
+        raise ValueError("need 0 <= rank < world_size, got %d / %d" % (rank, world_size))
+    if _native is not None:
+        raise RuntimeError("roundtrip_amd.dist.init was already called in this process (shutdown() first)")
+    uid = exchange_id(engine.comm_unique_id, rank, world_size, addr, port, timeout, _epoch)
+    _epoch += 1
+    engine.comm_init(world_size, rank, uid)
+    _native = (engine, rank, world_size)
+    return rank, world_size
+
+
+def shutdown():
+    """Destroys the communicator made by init() (collective)."""
+    global _native
+    if _native is not None:
+        eng = _native[0]
+        _native = None
+        eng.comm_destroy()
+
+
+def _torch_group():
+    """torch.distributed, if the CALLER has imported torch and initialised a process group; never imports torch."""
+    td = sys.modules.get("torch.distributed")
+    if td is not None and td.is_available() and td.is_initialized():
+        return td
+    return None
+
+
 def world():
-    """(rank, world_size) of the default process group, or (0, 1) when torch.distributed is not initialised."""
-    try:
-        import torch.distributed as dist
-    except ImportError:
-        return 0, 1
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+    """(rank, world_size): of the communicator made by init(), else of the caller's torch.distributed process group,
+    else (0, 1)."""
+    if _native is not None:
+        return _native[1], _native[2]
+    td = _torch_group()
+    if td is not None:
+        return td.get_rank(), td.get_world_size()
     return 0, 1
+
+
+def active():
+    """True when results must go through a gather: several ranks, or a communicator made by init() (a one-rank
+    communicator still runs the RCCL call — that is how the path is exercised on a one-GPU box)."""
+    return _native is not None or world()[1] > 1
+
+
+def _gather_rows(rows, device=None):
+    """(world, len(rows)) float64: every rank's `rows` (a flat float64 array, the same length on every rank)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1)
+    if _native is not None:
+        return _native[0].comm_all_gather(rows)           # RCCL on the engine's stream (rt_comm_all_gather_f64)
+    td = _torch_group()
+    torch = sys.modules["torch"]
+    if td.get_backend() != "nccl":
+        dev = torch.device("cpu")
+    else:   # the caller's RCCL group: buffers on the engine's device, not torch's current one
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    out = torch.empty(rows.size * td.get_world_size(), dtype=torch.float64, device=dev)
+    td.all_gather_into_tensor(out, torch.from_numpy(rows).to(dev))
+    return out.cpu().numpy().reshape(td.get_world_size(), rows.size)
 
 
 def all_gather_blocks(local, n, device=None):
     """Assembles the full (n,) float64 result from every rank's contiguous block (see shard_bounds).
 
-    device: the HIP device index this rank computes on (the engine's).  Under the "nccl" backend the gather buffers
-    live there — NOT on torch's current device, which is 0 on every rank unless the caller set it, and RCCL refuses
-    two ranks on one GPU.  Ignored under "gloo" (host buffers).
-
-    One all_gather of ceil(n / world) float64 per rank — the only collective on the path.  Payloads are tiny
+    One all-gather of ceil(n / world) float64 per rank — the only collective on the path.  Payloads are tiny
     (1M points = 8 MB in total), so this is latency- not bandwidth-bound; a single direct all-gather is right.
-    """
+    `device` only matters for a caller-owned torch "nccl" group (the HIP device index of the engine)."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return np.asarray(local, dtype=np.float64)
-    import torch
-    import torch.distributed as dist
     per = -(-int(n) // ws)
-    if dist.get_backend() != "nccl":
-        device = torch.device("cpu")
-    elif device is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    else:
-        device = torch.device("cuda", int(device))
-    buf = torch.zeros(per, dtype=torch.float64, device=device)
-    loc = torch.as_tensor(np.asarray(local, dtype=np.float64))
-    buf[: loc.numel()] = loc.to(device)
-    out = torch.empty(per * ws, dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    return out.cpu().numpy()[:n].copy()
+    buf = np.zeros(per, dtype=np.float64)
+    loc = np.asarray(local, dtype=np.float64).reshape(-1)
+    buf[: loc.size] = loc
+    return _gather_rows(buf, device).reshape(-1)[:n].copy()
 
 
 def sharded_map(points, fn, device=None):
@@ -78,24 +226,14 @@ def all_gather_ranges(local, total, axis=1, device=None):
     ranges of a point's (max, sum) pairs, 16 bytes each — again a single small all-gather."""
     rank, ws = world()
     local = np.asarray(local, dtype=np.float64)
-    if ws == 1:
+    if not active():
         return local
-    import torch
-    import torch.distributed as dist
     per = -(-int(total) // ws)
     moved = np.moveaxis(local, axis, 0)                       # (mine, ...)
     rest = moved.shape[1:]
-    if dist.get_backend() != "nccl":
-        device = torch.device("cpu")
-    elif device is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    else:
-        device = torch.device("cuda", int(device))
     buf = np.zeros((per,) + rest, dtype=np.float64)
     buf[: moved.shape[0]] = moved
-    out = torch.empty((ws * per,) + rest, dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(device))
-    out = out.cpu().numpy().reshape((ws, per) + rest)
+    out = _gather_rows(buf, device).reshape((ws, per) + rest)
     parts = []
     for r in range(ws):
         lo, hi = shard_bounds(total, ws, r)

@@ -27,7 +27,9 @@ class _IsModelBase(object):
     #: seed of the counter-based proposal sampler.  The reference reseeds numpy's global RNG with 0 at
     #: every call (main_density_est.py:267), i.e. "same call => same answer"; a fixed default keeps that.
     is_seed = 0
-    #: shard query points over torch.distributed ranks when a process group is initialised
+    #: shard query points over the ranks of the job (one process per GPU) when there are several: after
+    #: init_distributed() (RCCL behind the C ABI, no torch), or under a torch.distributed process group the caller has
+    #: initialised itself
     shard = True
     #: where the proposal draws come from.  "philox": the in-kernel counter-based sampler (the fast path).
     #: "numpy": the reference's own draws — numpy's legacy MT19937 stream seeded with 0, consumed exactly as
@@ -53,6 +55,12 @@ class _IsModelBase(object):
             dev = self._device if self._device is not None else _default_device()
             self._engine = _lib.Engine(dev)   # raises if librt_is.so or the GPU is missing
         return self._engine
+
+    def init_distributed(self, rank=None, world_size=None, addr=None, port=None):
+        """Collective over all ranks of the job: makes this model's engine a member of the job's RCCL communicator
+        (arguments default to the launcher's RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  The estimators then shard
+        query points over the ranks and every rank returns the full result."""
+        return dist.init(self.engine, rank, world_size, addr, port)
 
     def _nets(self):
         raise NotImplementedError
@@ -93,10 +101,10 @@ class _IsModelBase(object):
         elif self.is_sampler != "philox":
             raise ValueError("is_sampler must be 'philox' or 'numpy', not %r" % (self.is_sampler,))
         ws = dist.world()[1]
-        if self.shard and ws > 1 and self.is_sampler == "philox" and points.shape[0] > 0 and \
+        if self.shard and dist.active() and self.is_sampler == "philox" and points.shape[0] > 0 and \
                 (self.split_samples if self.split_samples is not None else points.shape[0] < ws):
             return self._estimate_is_split(points, [sd], scale, sample_size, df, log)[0]
-        if self.shard and ws > 1:
+        if self.shard and dist.active():
             return dist.sharded_map(points, block, device=eng.device)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
@@ -178,7 +186,7 @@ class _IsModelBase(object):
             # :384 — the reference's log=False branch carries an extra sd**y_dim factor; kept as written
             return 1. / (np.sqrt(2 * np.pi) * sd) ** y_dim * sd ** y_dim * np.sqrt(det) * np.exp(-0.5 * c_y)
 
-        if self.shard and dist.world()[1] > 1:
+        if self.shard and dist.active():
             return dist.sharded_map(points, block, device=eng.device)
         if points.shape[0] == 0:
             return np.zeros(0, dtype=np.float64)
@@ -197,7 +205,7 @@ class _IsModelBase(object):
         if points.shape[0] == 0:
             return np.zeros((len(sds), 0), dtype=np.float64)
         rank, ws = dist.world()
-        if not (self.shard and ws > 1):
+        if not (self.shard and dist.active()):
             centres = eng.mlp_forward(_lib.RT_MLP_H, points.astype(np.float32))
             return eng.is_estimate_multi(points, centres, sample_size, sds, scale, df=df, seed=self.is_seed, log=log)
         lo, hi = dist.shard_bounds(points.shape[0], ws, rank)
@@ -288,7 +296,10 @@ class Roundtrip(_IsModelBase):
         turns the two grids into PNGs with plot_2d_grid_data (plotting is out of scope here); the arrays are saved
         as .npy under the same stems and returned.  `self.data_sampler` (any object with load_all()) must be set,
         as train() does upstream."""
-        data_z_ = self.e_net(self.data_sampler.load_all())
+        data = self.data_sampler.load_all()
+        if isinstance(data, tuple):       # this repo's samplers return (X, Y) like util.py's; the reference passes X
+            data = data[0]
+        data_z_ = self.e_net(data)
         np.save('{}/data_z_at_{}.npy'.format(self.save_dir, batch_idx), data_z_)
         ranges = {'indep_gmm': (-1.5, 1.5, -1.5, 1.5), 'involute': (-6, 5, -5, 5)}
         out = {'data_z': data_z_}

@@ -326,26 +326,65 @@ def test_all_gather_ranges_world_size_2_gloo(tmp_path):
     assert res.stdout.count("rank ok") == 2
 
 
-def test_evaluate_callers_host_logic():
-    """precision_at_K / create_2d_grid_data (evaluate.py:15-20, 55-59) and the callers' plumbing with a stub model."""
-    from roundtrip_amd import evaluate as ev
-    v1, v2, grid = ev.create_2d_grid_data(-5, 5, -5, 5, n=100)
-    assert grid.shape == (10000, 2) and grid[0].tolist() == [-5.0, -5.0] and grid[99].tolist() == [5.0, -5.0]
-    score = np.array([0.5, -3.0, 0.1, -2.5, 2.0, -0.2])          # lower = more abnormal
-    label = np.array([0, 1, 0, 0, 0, 1])                         # two outliers
-    assert ev.precision_at_K(score, label) == 0.5               # the two lowest are index 1 (outlier) and 3 (inlier)
+def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
+    """The TCP exchange of RCCL's unique id (roundtrip_amd.dist.exchange_id), four processes on CPU: every rank ends
+    with rank 0's 128 bytes, although a foreign server (one that answers garbage) sits on the first candidate port and
+    rank 0 starts late.  A second round (epoch 1) in the same processes works too."""
+    port = _free_port()
+    foreign = socket.socket()
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        foreign.bind(("127.0.0.1", port + 1))
+        foreign.listen(8)
+    except OSError:
+        foreign = None                              # taken by someone else: equally foreign
+    script = tmp_path / "r.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        from roundtrip_amd import dist as rdist
+        rank, ws, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        if rank == 0:
+            time.sleep(1.0)
+        for epoch in (0, 1):
+            uid = rdist.exchange_id(lambda: bytes([(7 * i + rank + epoch) %% 256 for i in range(128)]), rank, ws,
+                                    "127.0.0.1", port, timeout=60.0, epoch=epoch)
+            assert uid == bytes([(7 * i + epoch) %% 256 for i in range(128)]), (rank, epoch)
+        print("rank ok")
+    """ % (ROOT,)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "4", str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(4)]
+    try:
+        if foreign is not None:                     # answer the first peers that knock with something that is not ours
+            foreign.settimeout(0.5)
+            t_end = __import__("time").time() + 3.0
+            while __import__("time").time() < t_end:
+                try:
+                    c, _ = foreign.accept()
+                    c.sendall(b"HTTP/1.1 400 nope")
+                    c.close()
+                except socket.timeout:
+                    pass
+        outs = [p.communicate(timeout=120) for p in procs]
+    finally:
+        if foreign is not None:
+            foreign.close()
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "rank ok" in o, o + e
 
-    class Stub(object):
-        def estimate_py_with_IS(self, y, epoch, sd_y=0.5, scale=0.5, sample_size=40000, bs=1024, log=True, save=True):
-            self.seen = dict(n=len(y), sd_y=sd_y, scale=scale, sample_size=sample_size, log=log, save=save)
-            return -np.sum(np.asarray(y) ** 2, axis=1) if log else np.exp(-np.sum(np.asarray(y) ** 2, axis=1))
-    m = Stub()
-    (rng, sd, sc) = ev.GRID_SETTINGS["eight_octagon_gmm"]
-    _, _, py = ev.visualization_2d(m, *rng, sd_y=sd, scale=sc, n=20)
-    assert py.shape == (20, 20) and m.seen == dict(n=400, sd_y=0.1, scale=0.5, sample_size=10000, log=False, save=False)
-    X = np.array([[0.0, 0.1], [3.0, 3.0], [0.2, 0.0], [-4.0, 1.0]])
-    prec, py = ev.odd_evaluate(m, X, np.array([0, 1, 0, 1]), 0.1, 0.5)
-    assert prec == 1.0 and m.seen["log"] is True
+
+def test_bench_parent_starts_ranks_before_touching_the_gpu():
+    """bench.py --gpus N without a launcher: the parent spawns N rank processes with the launcher's environment and
+    relays the first failure's exit code.  Without a GPU the ranks fail at rt_ctx_create — loudly, not silently."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present: covered by the -m gpu bench test")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--grid", "4", "--share-gpu"], capture_output=True, text=True, timeout=240)
+    assert res.returncode != 0
+    assert "rt_ctx_create" in res.stderr and "torch" not in res.stderr.lower().replace("torch.distributed.run", "")
 
 
 def test_reference_draws_mode_host_logic(tmp_path, monkeypatch):

@@ -294,3 +294,102 @@ def test_model_level_sharding_two_ranks(tmp_path):
                          cwd=str(tmp_path))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert res.stdout.count("rank ok") == 2
+
+
+def _run_script(tmp_path, body, timeout=300, env=None):
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys\nsys.path.insert(0, %r)\n" % root + textwrap.dedent(body))
+    return subprocess.run([sys.executable, str(script)], env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})),
+                          capture_output=True, text=True, timeout=timeout, cwd=str(tmp_path))
+
+
+def test_rccl_branch_world_size_1(tmp_path):
+    """The real RCCL path (rt_comm_* behind the C ABI, librccl dlopen'ed, the engine's device and stream) with a
+    one-rank communicator — all a one-GPU box allows, RCCL refusing two ranks on one GPU: dist.init from a launcher's
+    environment, all_gather_blocks, all_gather_ranges, the device-resident gather, the max-reduce and the barrier, and
+    the drop-in class's sharded estimate_py_with_IS / split-samples / several-sd / Laplace paths through the gather.
+    Runs in a process of its own, which never imports torch."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    res = _run_script(tmp_path, """
+        import numpy as np
+        from roundtrip_amd import Generator, RoundtripModel, _lib, dist as rdist
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+        rng = np.random.RandomState(21)
+        g = Generator(3, 6, "g_net", nb_layers=10, nb_units=512, rng=rng)
+        h = Generator(6, 3, "h_net", nb_layers=10, nb_units=256, rng=rng)
+        m = RoundtripModel(g, h, data="arem", df=1, device=0)
+        y = np.random.RandomState(22).standard_normal((13, 6)) * 0.1
+        one = dict(IS=m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False),
+                   multi=m._estimate_is_multi(y, [0.05, 0.1], 0.1, 900, 1, True),
+                   CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
+        assert not rdist.active() and rdist.world() == (0, 1)
+        assert m.init_distributed() == (0, 1)
+        assert rdist.active() and m.engine.comm_info() == (0, 1)
+        eng = m.engine
+        # the raw collectives
+        v = np.arange(7, dtype=np.float64) * 1.5
+        assert np.array_equal(eng.comm_all_gather(v), v[None, :])
+        assert np.array_equal(eng.comm_all_reduce_max([3.25, -1.0]), [3.25, -1.0])
+        eng.comm_barrier()
+        src, dst = eng.to_device(v), eng.dev_alloc(v.nbytes)
+        eng.comm_all_gather_dev(src, v.size, dst)
+        eng.sync()
+        assert np.array_equal(eng.from_device(dst, v.shape, np.float64), v)
+        eng.dev_free(src); eng.dev_free(dst)
+        # dist's gathers
+        assert np.array_equal(rdist.all_gather_blocks(v, 7), v)
+        whole = np.random.RandomState(1).standard_normal((3, 5, 2, 2))
+        assert np.array_equal(rdist.all_gather_ranges(whole, 5, axis=1), whole)
+        calls = []
+        out = rdist.sharded_map(y, lambda blk, base: (calls.append((base, len(blk))), blk.sum(axis=1))[1])
+        assert calls == [(0, 13)] and np.array_equal(out, y.sum(axis=1))
+        # the drop-in class through the gather
+        got = dict(IS=m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False),
+                   multi=m._estimate_is_multi(y, [0.05, 0.1], 0.1, 900, 1, True),
+                   CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
+        for k in got:
+            assert got[k].shape == one[k].shape and np.array_equal(got[k], one[k]), k
+        m.split_samples = True
+        assert np.array_equal(m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False), one["IS"])
+        try:
+            rdist.init(eng)
+            raise SystemExit("second init must be refused")
+        except RuntimeError:
+            pass
+        rdist.shutdown()
+        assert not rdist.active()
+        assert "torch" not in sys.modules
+        print("rccl ok")
+    """)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment starts two rank processes itself and prints ONE
+    JSON line with n_gpus = 2 (gloo on host tensors and one shared GPU here: the rehearsal mode; on a node it is one GPU
+    per rank over RCCL); `--gpus 1` prints the line with the roofline and both CPU legs."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--steps", "1", "--warmup", "0", "--grid", "16", "--sample-size", "640"],
+                         env=dict(env, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["query_points_total"] == 512 and d["result_check"]["finite"]
+    assert d["value"] > 0 and d["roofline"]["launches"] == 1
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--grid", "16", "--sample-size", "640", "--no-live-traffic", "--cpu-points", "8",
+                          "--cpu-points-numpy", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
+    assert "matches GPU on this sample: True" in d["cpu_baseline"]["sample"]
+    assert "matches GPU on this sample: True" in d["cpu_baseline"]["numpy_restatement"]["sample"]
