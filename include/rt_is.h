@@ -203,6 +203,11 @@ int rt_reset_counters(rt_ctx* ctx);
 /* Device facts the host side needs for work partitioning. */
 int rt_device_cu_count(rt_ctx* ctx, int* out);
 
+/* CRC-32C (Castagnoli) of n bytes, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint files carry
+ * per index block and per tensor, which `tf.train.Saver.restore` / `ckpt.restore` verify (main_density_est.py:402,410;
+ * roundtrip.py:57) and roundtrip_amd/checkpoint.py verifies through this.  Host code, needs no context or GPU. */
+uint32_t rt_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* --- Device memory for callers of the *_dev entry points (the reference keeps its arrays in numpy and feeds TF
  * placeholders, main_density_est.py:232,247; a host program that wants its query points resident in HBM needs no other
  * GPU library than this one).  rt_dev_free waits for the context's stream first; the copies are synchronous. */

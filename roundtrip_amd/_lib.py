@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
     "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs", "rt_is_estimate_dev_noalloc",
-    "rt_philox4x32_10",
+    "rt_philox4x32_10", "rt_crc32c",
     "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
     "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
@@ -81,6 +81,8 @@ def load():
     lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
     lib.rt_is_estimate_dev_noalloc.argtypes = lib.rt_is_estimate_dev.argtypes
     lib.rt_philox4x32_10.argtypes = [vp, vp, i64, vp]
+    lib.rt_crc32c.restype = C.c_uint32
+    lib.rt_crc32c.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
     lib.rt_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.rt_dev_free.argtypes = [vp, vp]
     lib.rt_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -95,7 +97,7 @@ def load():
     lib.rt_comm_barrier.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name != "rt_last_error":
+        if name not in ("rt_last_error", "rt_crc32c"):
             fn.restype = C.c_int
     _lib = lib
     return lib

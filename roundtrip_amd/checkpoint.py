@@ -6,16 +6,23 @@ The reference stores G / H weights with `tf.train.Saver` (v1: /root/reference/ma
 tensor name -> BundleEntryProto {dtype, shape, shard_id, offset, size, crc32c}, and
 `<prefix>.data-00000-of-00001` holding the raw little-endian tensor bytes.
 
-No TensorFlow, no protobuf package: the SSTable blocks, the two small protos and (optional) snappy blocks
-are decoded here by hand.  NOT VERIFIED against a TF-written file: none exists offline (SURVEY.md §7);
-the writer below produces the same layout so that tests can round-trip and fixtures can be exchanged
-with a TensorFlow install elsewhere.
+No TensorFlow, no protobuf package: the SSTable blocks, the small protos (BundleHeaderProto, BundleEntryProto,
+TrackableObjectGraph) and (optional) snappy blocks are decoded here by hand.  PARITY UNPINNED: not verified against a
+TF-written file — none exists offline; the writer below produces the same layout so that tests can
+round-trip and fixtures can be exchanged with a TensorFlow install elsewhere, and tests/test_abi_host.py also feeds the
+reader an index assembled byte by byte by independent code (snappy blocks, restart interval 16, Adam slots, a string
+tensor, two data shards).
 
 Variable names:
   v1  <scope>/fully_connected/weights, <scope>/fully_connected/biases, <scope>/fully_connected_<i>/...
       for i = 1..nb_layers (tcl.fully_connected's default scopes under tf.variable_scope(name), model.py:63)
-  v2  <attr>/all_layers/<i>/0/kernel/.ATTRIBUTES/VARIABLE_VALUE and .../bias/... (object-graph path of
-      `self.all_layers.append([fc_layer, norm_layer])`, src/pyroundtrip/model.py:25) — expected, unverified.
+  v2  tf.train.Checkpoint stores the object graph it saved in the string tensor `_CHECKPOINTABLE_OBJECT_GRAPH`
+      (TrackableObjectGraph: nodes -> children (local_name, node_id) / attributes (name, checkpoint_key)).  The
+      reader walks it along the attribute path the CODE defines — root -> g_net -> all_layers -> <i> -> 0 -> kernel / bias
+      (`Checkpoint(g_net=...)`, roundtrip.py:48; `self.all_layers.append([fc_layer, norm_layer])`,
+      src/pyroundtrip/model.py:25) — and reads whatever checkpoint_key the VARIABLE_VALUE attribute names.  Only when a
+      file has no object graph does it fall back to the expected key text
+      <attr>/all_layers/<i>/0/kernel/.ATTRIBUTES/VARIABLE_VALUE (or any kernels under <attr>/ whose shapes chain).
 """
 import os
 import re
@@ -45,12 +52,37 @@ def _make_crc_table():
 _CRC_TABLE = _make_crc_table()
 
 
-def crc32c(data, crc=0):
+def _crc32c_py(data, crc=0):
     crc ^= 0xFFFFFFFF
     tbl = _CRC_TABLE
     for b in bytes(data):
         crc = tbl[(crc ^ b) & 0xFF] ^ (crc >> 8)
     return crc ^ 0xFFFFFFFF
+
+
+_crc_native = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli) of `data`, continuing from `crc`.  Long inputs (the per-tensor checksums of a 12 MB
+    checkpoint) go through rt_crc32c of librt_is.so when the library is there (host code, no GPU); the pure-Python loop
+    gives the same values (tests compare them) and serves everything else."""
+    global _crc_native
+    data = bytes(data)
+    if len(data) >= 4096 and _crc_native is not False:
+        if _crc_native is None:
+            try:
+                import ctypes
+                from . import _lib
+                fn = _lib.load().rt_crc32c
+                fn.restype = ctypes.c_uint32
+                fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+                _crc_native = fn
+            except (ImportError, OSError, AttributeError):
+                _crc_native = False
+        if _crc_native:
+            return int(_crc_native(data, len(data), crc))
+    return _crc32c_py(data, crc)
 
 
 def mask_crc(crc):
@@ -143,15 +175,101 @@ def parse_bundle_entry(buf):
     return e
 
 
-def _encode_bundle_entry(dtype, shape, offset, size, crc):
+def _encode_bundle_entry(dtype, shape, offset, size, crc, shard_id=0):
     dims = b''.join(b'\x12' + _put_varint(len(d)) + d for d in (b'\x08' + _put_varint(s) for s in shape))
     out = b'\x08' + _put_varint(dtype)
     out += b'\x12' + _put_varint(len(dims)) + dims
+    if shard_id:
+        out += b'\x18' + _put_varint(shard_id)
     if offset:
         out += b'\x20' + _put_varint(offset)
     out += b'\x28' + _put_varint(size)
     out += b'\x35' + struct.pack('<I', crc)
     return out
+
+
+# ---- TrackableObjectGraph (tensorflow/core/protobuf/trackable_object_graph.proto) ------------------------------
+OBJECT_GRAPH_KEY = '_CHECKPOINTABLE_OBJECT_GRAPH'
+
+
+def parse_object_graph(buf):
+    """-> list of nodes, node i = {'children': {local_name: node_id}, 'attributes': {name: checkpoint_key},
+    'slots': [(original_variable_node_id, slot_name, slot_variable_node_id)]}.
+    TrackableObjectGraph { repeated TrackableObject nodes = 1 }; TrackableObject { repeated ObjectReference children = 1
+    {node_id = 1, local_name = 2}; repeated SerializedTensor attributes = 2 {name = 1, full_name = 2, checkpoint_key = 3};
+    repeated SlotVariableReference slot_variables = 3 {original_variable_node_id = 1, slot_name = 2,
+    slot_variable_node_id = 3} }."""
+    nodes = []
+    for fn, wt, v in _parse_proto(buf):
+        if fn != 1 or wt != 2:
+            continue
+        node = {'children': {}, 'attributes': {}, 'slots': []}
+        for f2, w2, v2 in _parse_proto(v):
+            if w2 != 2:
+                continue
+            sub = _parse_proto(v2)
+            if f2 == 1:
+                nid, name = 0, ''
+                for f3, _, v3 in sub:
+                    if f3 == 1:
+                        nid = v3
+                    elif f3 == 2:
+                        name = v3.decode('utf-8')
+                node['children'][name] = nid
+            elif f2 == 2:
+                name, key = '', ''
+                for f3, _, v3 in sub:
+                    if f3 == 1:
+                        name = v3.decode('utf-8')
+                    elif f3 == 3:
+                        key = v3.decode('utf-8')
+                node['attributes'][name] = key
+            elif f2 == 3:
+                orig, slot, var = 0, '', 0
+                for f3, _, v3 in sub:
+                    if f3 == 1:
+                        orig = v3
+                    elif f3 == 2:
+                        slot = v3.decode('utf-8')
+                    elif f3 == 3:
+                        var = v3
+                node['slots'].append((orig, slot, var))
+        nodes.append(node)
+    return nodes
+
+
+def _encode_object_graph(nodes):
+    def field(fn, payload):
+        return _put_varint((fn << 3) | 2) + _put_varint(len(payload)) + payload
+    out = b''
+    for node in nodes:
+        body = b''
+        for name, nid in node.get('children', {}).items():
+            body += field(1, (b'\x08' + _put_varint(nid) if nid else b'') + field(2, name.encode('utf-8')))
+        for name, key in node.get('attributes', {}).items():
+            body += field(2, field(1, name.encode('utf-8')) + field(2, key.split('/.ATTRIBUTES')[0].encode('utf-8'))
+                          + field(3, key.encode('utf-8')))
+        for orig, slot, var in node.get('slots', []):
+            body += field(3, b'\x08' + _put_varint(orig) + field(2, slot.encode('utf-8')) + b'\x18' + _put_varint(var))
+        out += field(1, body)
+    return out
+
+
+def resolve_path(nodes, path, attribute='VARIABLE_VALUE'):
+    """checkpoint_key of `attribute` on the node reached from the root (node 0) along the child names in `path`."""
+    nid = 0
+    for i, name in enumerate(path):
+        kids = nodes[nid]['children']
+        if name not in kids:
+            raise KeyError("object graph: no child %r under /%s (children: %s)"
+                           % (name, '/'.join(path[:i]), sorted(kids)))
+        nid = kids[name]
+        if not 0 <= nid < len(nodes):
+            raise ValueError("object graph: child %r points at node %d of %d" % (name, nid, len(nodes)))
+    attrs = nodes[nid]['attributes']
+    if attribute not in attrs:
+        raise KeyError("object graph: /%s has no %s attribute (has %s)" % ('/'.join(path), attribute, sorted(attrs)))
+    return attrs[attribute]
 
 
 # ---- snappy (raw format), for index blocks written with compression -----------------------------------
@@ -324,18 +442,61 @@ class BundleReader(object):
     def shape(self, key):
         return tuple(self.entries[key]['shape'])
 
-    def get_tensor(self, key, verify=False):
+    def _raw(self, key, verify):
         e = self.entries[key]
-        if e['sliced']:
-            raise ValueError("%s: partitioned (sliced) variables are not supported" % key)
-        if e['dtype'] not in _NP_OF_DT:
-            raise ValueError("%s: dtype %d is not a plain numeric tensor" % (key, e['dtype']))
         path = '%s.data-%05d-of-%05d' % (self.prefix, e['shard_id'], self.num_shards)
         with open(path, 'rb') as f:
             f.seek(e['offset'])
             raw = f.read(e['size'])
         if len(raw) != e['size']:
-            raise ValueError("%s: data file truncated" % key)
+            raise ValueError("%s: data file %s truncated" % (key, os.path.basename(path)))
+        return raw
+
+    def get_strings(self, key, verify=True):
+        """The elements (bytes) of a DT_STRING tensor.  On disk (tensor_bundle.cc, WriteStringTensor): the elements'
+        lengths as varint64s, a 4-byte masked crc32c of those lengths (taken over each length as a little-endian
+        uint32, or uint64 beyond 2^32), then the elements' bytes; the entry's crc32c covers the lengths in that
+        fixed-width form, the 4 checksum bytes and the elements' bytes."""
+        e = self.entries[key]
+        if e['dtype'] != DT_STRING:
+            raise ValueError("%s: not a string tensor" % key)
+        raw = self._raw(key, verify)
+        n = int(np.prod(e['shape'])) if e['shape'] else 1
+        pos, lens = 0, []
+        for _ in range(n):
+            ln, pos = _get_varint(raw, pos)
+            lens.append(ln)
+        fixed = b''.join(struct.pack('<I', ln) if ln <= 0xFFFFFFFF else struct.pack('<Q', ln) for ln in lens)
+        cks = raw[pos:pos + 4]
+        pos += 4
+        if verify:
+            if len(cks) != 4 or struct.unpack('<I', cks)[0] != mask_crc(crc32c(fixed)):
+                raise ValueError("%s: string-length checksum mismatch" % key)
+            if mask_crc(crc32c(raw[pos:], crc32c(cks, crc32c(fixed)))) != e['crc32c']:
+                raise ValueError("%s: data checksum mismatch" % key)
+        out = []
+        for ln in lens:
+            out.append(raw[pos:pos + ln])
+            pos += ln
+        if pos != len(raw):
+            raise ValueError("%s: string tensor size mismatch" % key)
+        return out
+
+    def object_graph(self):
+        """The TrackableObjectGraph a tf.train.Checkpoint stored (list of nodes, see parse_object_graph), or None."""
+        if OBJECT_GRAPH_KEY not in self.entries:
+            return None
+        # (the string tensor's own checksums are not insisted on here: its on-disk layout is restated from
+        # tensor_bundle.cc without a TF-written file to confirm it, and a damaged graph fails loudly in resolve_path)
+        return parse_object_graph(self.get_strings(OBJECT_GRAPH_KEY, verify=False)[0])
+
+    def get_tensor(self, key, verify=True):
+        e = self.entries[key]
+        if e['sliced']:
+            raise ValueError("%s: partitioned (sliced) variables are not supported" % key)
+        if e['dtype'] not in _NP_OF_DT:
+            raise ValueError("%s: dtype %d is not a plain numeric tensor" % (key, e['dtype']))
+        raw = self._raw(key, verify)
         if verify and mask_crc(crc32c(raw)) != e['crc32c']:
             raise ValueError("%s: data checksum mismatch" % key)
         arr = np.frombuffer(raw, dtype=_NP_OF_DT[e['dtype']])
@@ -345,25 +506,41 @@ class BundleReader(object):
         return arr.reshape(e['shape']).copy()
 
 
-def write_bundle(prefix, tensors):
-    """Writes {name: ndarray} as a one-shard TensorBundle (<prefix>.index + <prefix>.data-00000-of-00001)."""
+def write_bundle(prefix, tensors, shards=1):
+    """Writes {name: ndarray | bytes} as a TensorBundle: <prefix>.index + <prefix>.data-0000k-of-0000n, tensors dealt
+    round-robin over `shards` data files (a bytes value becomes a scalar DT_STRING tensor)."""
     d = os.path.dirname(prefix)
     if d and not os.path.exists(d):
         os.makedirs(d)
-    header = b'\x08\x01' + b'\x1a\x02\x08\x01'   # num_shards = 1, version { producer: 1 }
+    header = b'\x08' + _put_varint(shards) + b'\x1a\x02\x08\x01'   # num_shards, version { producer: 1 }
     items = [(b'', header)]
-    offset = 0
-    with open(prefix + '.data-00000-of-00001', 'wb') as f:
-        for name in sorted(tensors):
-            arr = np.ascontiguousarray(tensors[name])
-            dt = _DT_OF_NP.get(arr.dtype)
-            if dt is None:
-                raise ValueError("%s: unsupported dtype %s" % (name, arr.dtype))
-            raw = arr.astype(arr.dtype.newbyteorder('<')).tobytes()
-            f.write(raw)
+    files = [open('%s.data-%05d-of-%05d' % (prefix, k, shards), 'wb') for k in range(shards)]
+    offsets = [0] * shards
+    try:
+        for i, name in enumerate(sorted(tensors)):
+            k = i % shards
+            val = tensors[name]
+            if isinstance(val, (bytes, bytearray)):
+                val = bytes(val)
+                fixed = struct.pack('<I', len(val))
+                cks = struct.pack('<I', mask_crc(crc32c(fixed)))
+                raw = _put_varint(len(val)) + cks + val
+                crc = crc32c(val, crc32c(cks, crc32c(fixed)))
+                dt, shape = DT_STRING, ()
+            else:
+                arr = np.ascontiguousarray(val)
+                dt = _DT_OF_NP.get(arr.dtype)
+                if dt is None:
+                    raise ValueError("%s: unsupported dtype %s" % (name, arr.dtype))
+                raw = arr.astype(arr.dtype.newbyteorder('<')).tobytes()
+                crc, shape = crc32c(raw), arr.shape
+            files[k].write(raw)
             items.append((name.encode('utf-8'),
-                          _encode_bundle_entry(dt, arr.shape, offset, len(raw), mask_crc(crc32c(raw)))))
-            offset += len(raw)
+                          _encode_bundle_entry(dt, shape, offsets[k], len(raw), mask_crc(crc), shard_id=k)))
+            offsets[k] += len(raw)
+    finally:
+        for f in files:
+            f.close()
     write_table(prefix + '.index', items)
 
 
@@ -402,20 +579,28 @@ def v2_names(attr, n_layers):
             for i in range(n_layers)]
 
 
-def _load_net(reader, net, names):
+def _load_net(reader, net, names, verify=True):
     ws, bs = [], []
     for wn, bn in names:
         if wn not in reader.entries or bn not in reader.entries:
             raise KeyError("checkpoint %s has no variable %s (have e.g. %s)"
                            % (reader.prefix, wn if wn not in reader.entries else bn, reader.keys()[:4]))
-        ws.append(reader.get_tensor(wn))
-        bs.append(reader.get_tensor(bn))
+        ws.append(reader.get_tensor(wn, verify))
+        bs.append(reader.get_tensor(bn, verify))
     net.set_weights(ws, bs)
 
 
+def _v2_names_from_graph(nodes, attr, n_layers):
+    """[(kernel key, bias key)] of net `attr`'s dense layers, read off the object graph along the path the code defines:
+    Checkpoint(<attr>=net) (roundtrip.py:48) -> net.all_layers (a list) -> [i] (the [fc_layer, norm_layer] pair,
+    src/pyroundtrip/model.py:25) -> [0] (the Dense layer) -> kernel / bias."""
+    return [(resolve_path(nodes, [attr, 'all_layers', str(i), '0', 'kernel']),
+             resolve_path(nodes, [attr, 'all_layers', str(i), '0', 'bias'])) for i in range(n_layers)]
+
+
 def _v2_names_tolerant(reader, attr, net):
-    """The expected v2 keys, or — the object-graph path being unverified — any '<attr>/...kernel' variables
-    whose shapes chain through the net's widths, ordered by the numbers in their paths."""
+    """For a file WITHOUT an object graph: the expected v2 key text, or any '<attr>/...kernel' variables whose shapes
+    chain through the net's widths, ordered by the numbers in their paths."""
     n = len(net.dims) - 1
     names = v2_names(attr, n)
     if all(w in reader.entries and b in reader.entries for w, b in names):
@@ -431,18 +616,24 @@ def _v2_names_tolerant(reader, attr, net):
     return [(k, k[:-len('kernel' + suffix)] + 'bias' + suffix) for k in kernels]
 
 
-def load_v1(prefix, g_net, h_net, verify=False):
-    """tf.train.Saver checkpoint of the v1 model (main_density_est.py:402,410). Adam slots are ignored."""
-    r = BundleReader(prefix)
-    _load_net(r, g_net, v1_names(g_net.name, len(g_net.dims) - 1))
-    _load_net(r, h_net, v1_names(h_net.name, len(h_net.dims) - 1))
+def load_v1(prefix, g_net, h_net, verify=True):
+    """tf.train.Saver checkpoint of the v1 model (main_density_est.py:402,410). Adam slots are ignored.
+    verify: check the index blocks' and every loaded tensor's crc32c (a corrupted data file raises)."""
+    r = BundleReader(prefix, verify)
+    _load_net(r, g_net, v1_names(g_net.name, len(g_net.dims) - 1), verify)
+    _load_net(r, h_net, v1_names(h_net.name, len(h_net.dims) - 1), verify)
 
 
-def load_v2(prefix, g_net, e_net):
-    """tf.train.Checkpoint of the v2 model (roundtrip.py:48-57)."""
-    r = BundleReader(prefix)
-    _load_net(r, g_net, _v2_names_tolerant(r, 'g_net', g_net))
-    _load_net(r, e_net, _v2_names_tolerant(r, 'e_net', e_net))
+def load_v2(prefix, g_net, e_net, verify=True):
+    """tf.train.Checkpoint of the v2 model (roundtrip.py:48-57): keys resolved through the stored object graph."""
+    r = BundleReader(prefix, verify)
+    nodes = r.object_graph()
+    for attr, net in (('g_net', g_net), ('e_net', e_net)):
+        if nodes is not None:
+            names = _v2_names_from_graph(nodes, attr, len(net.dims) - 1)
+        else:
+            names = _v2_names_tolerant(r, attr, net)
+        _load_net(r, net, names, verify)
 
 
 def _net_tensors(net, names):
@@ -459,7 +650,29 @@ def save_v1(prefix, g_net, h_net):
     write_bundle(prefix, t)
 
 
-def save_v2(prefix, g_net, e_net):
+def v2_object_graph(nets):
+    """The TrackableObjectGraph nodes for Checkpoint(**nets) with the key text of v2_names: root -> <attr> ->
+    all_layers -> <i> -> 0 -> kernel / bias, each variable node carrying a VARIABLE_VALUE attribute."""
+    nodes = [{'children': {}}]
+
+    def add(parent, name):
+        nodes.append({'children': {}, 'attributes': {}})
+        nodes[parent]['children'][name] = len(nodes) - 1
+        return len(nodes) - 1
+
+    for attr, net in nets:
+        a = add(0, attr)
+        lst = add(a, 'all_layers')
+        for i, (wn, bn) in enumerate(v2_names(attr, len(net.dims) - 1)):
+            pair = add(lst, str(i))
+            dense = add(pair, '0')
+            nodes[add(dense, 'kernel')]['attributes']['VARIABLE_VALUE'] = wn
+            nodes[add(dense, 'bias')]['attributes']['VARIABLE_VALUE'] = bn
+    return nodes
+
+
+def save_v2(prefix, g_net, e_net, shards=1):
     t = _net_tensors(g_net, v2_names('g_net', len(g_net.dims) - 1))
     t.update(_net_tensors(e_net, v2_names('e_net', len(e_net.dims) - 1)))
-    write_bundle(prefix, t)
+    t[OBJECT_GRAPH_KEY] = _encode_object_graph(v2_object_graph([('g_net', g_net), ('e_net', e_net)]))
+    write_bundle(prefix, t, shards=shards)

@@ -872,6 +872,35 @@ int rt_device_cu_count(rt_ctx* ctx, int* out) {
     return RT_OK;
 }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing by 8: host code for the checkpoint reader.
+uint32_t rt_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+    });
+    const unsigned char* p = (const unsigned char*)data;
+    crc = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+              T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+
 // ---- device memory for callers of the *_dev entry points ---------------------------------------------------------
 int rt_dev_alloc(rt_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return RT_EINVAL;

@@ -239,6 +239,295 @@ def test_v2_object_graph_keys_and_tolerant_lookup(tmp_path):
         ck.load_v2(prefix, BaseFullyConnectedNet(2, 2, "g_net", [16, 16, 16]), e2)
 
 
+# ---- a TensorBundle assembled byte by byte by code that shares nothing with roundtrip_amd/checkpoint.py --------------
+def _vi(v):
+    out = b""
+    while v >= 0x80:
+        out += bytes([(v & 0x7F) | 0x80])
+        v >>= 7
+    return out + bytes([v])
+
+
+def _crc32c_bitwise(data, crc=0):
+    crc ^= 0xFFFFFFFF
+    for byte in data:
+        crc ^= byte
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+    return crc ^ 0xFFFFFFFF
+
+
+def _masked(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _ld(field, payload):                       # length-delimited proto field
+    return _vi((field << 3) | 2) + _vi(len(payload)) + payload
+
+
+def _snappy_greedy(raw):
+    """A valid raw-snappy stream for `raw`: copies (2-byte offsets, <= 64 bytes) where an earlier occurrence of the next
+    >= 4 bytes exists, literals (short and 60/61-tagged long ones) elsewhere."""
+    out, lit, i = _vi(len(raw)), b"", 0
+
+    def flush(lit):
+        if not lit:
+            return b""
+        n = len(lit) - 1
+        if n < 60:
+            return bytes([n << 2]) + lit
+        if n < 256:
+            return bytes([60 << 2, n]) + lit
+        return bytes([61 << 2, n & 0xFF, n >> 8]) + lit
+
+    while i < len(raw):
+        best, off = 0, 0
+        if i + 4 <= len(raw):
+            j = raw.rfind(raw[i:i + 4], max(0, i - 60000), i + 3)
+            if 0 <= j < i:
+                ln = 4
+                while ln < 64 and i + ln < len(raw) and raw[j + ln] == raw[i + ln]:   # may overlap: snappy allows it
+                    ln += 1
+                best, off = ln, i - j
+        if best:
+            out += flush(lit)
+            lit = b""
+            out += bytes([((best - 1) << 2) | 2, off & 0xFF, off >> 8])
+            i += best
+        else:
+            lit += raw[i:i + 1]
+            i += 1
+            if len(lit) == 300:
+                out += flush(lit)
+                lit = b""
+    return out + flush(lit)
+
+
+def _hand_table(items, per_block, compress):
+    """LevelDB table: data blocks of `per_block` entries with prefix compression and a restart point every 16 entries,
+    an empty metaindex block, an index block, the 48-byte footer."""
+    items = sorted(items)
+    blob, index = b"", []
+
+    def block(entries, interval):
+        out, restarts, last = b"", [], b""
+        for n, (k, v) in enumerate(entries):
+            shared = 0
+            if n % interval == 0:
+                restarts.append(len(out))
+            else:
+                while shared < min(len(k), len(last)) and k[shared] == last[shared]:
+                    shared += 1
+            out += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
+            last = k
+        for r in restarts or [0]:
+            out += r.to_bytes(4, "little")
+        return out + len(restarts or [0]).to_bytes(4, "little")
+
+    def emit(raw, compress):
+        nonlocal blob
+        body, kind = (_snappy_greedy(raw), 1) if compress else (raw, 0)
+        handle = _vi(len(blob)) + _vi(len(body))
+        blob += body + bytes([kind]) + _masked(_crc32c_bitwise(body + bytes([kind]))).to_bytes(4, "little")
+        return handle
+
+    for i in range(0, len(items), per_block):
+        chunk = items[i:i + per_block]
+        index.append((chunk[-1][0], emit(block(chunk, 16), compress)))
+    meta = emit(block([], 16), False)
+    idx = emit(block(index, 1), False)
+    footer = meta + idx
+    return blob + footer + b"\x00" * (40 - len(footer)) + (0xdb4775248b80fb57).to_bytes(8, "little")
+
+
+def _hand_entry(dtype, shape, shard, offset, size, crc):
+    dims = b"".join(_ld(2, b"\x08" + _vi(d)) for d in shape)
+    e = b"\x08" + _vi(dtype) + _ld(2, dims)
+    if shard:
+        e += b"\x18" + _vi(shard)
+    if offset:
+        e += b"\x20" + _vi(offset)
+    return e + b"\x28" + _vi(size) + b"\x35" + crc.to_bytes(4, "little")
+
+
+def _hand_bundle(prefix, tensors, shards, per_block=40, compress=True):
+    """tensors: {name: float32/int64 ndarray | bytes}; dealt over `shards` data files in name order, hash-like."""
+    data = [b""] * shards
+    items = [(b"", b"\x08" + _vi(shards) + _ld(3, b"\x08\x01"))]        # BundleHeaderProto: num_shards, version
+    for n, name in enumerate(sorted(tensors)):
+        k = (n * 7 + 3) % shards
+        val = tensors[name]
+        if isinstance(val, bytes):
+            fixed = len(val).to_bytes(4, "little")
+            cks = _masked(_crc32c_bitwise(fixed)).to_bytes(4, "little")
+            raw, dtype, shape = _vi(len(val)) + cks + val, 7, ()
+            crc = _crc32c_bitwise(fixed + cks + val)
+        else:
+            raw, dtype, shape = val.tobytes(), {"float32": 1, "int64": 9}[str(val.dtype)], val.shape
+            crc = _crc32c_bitwise(raw)
+        items.append((name.encode(), _hand_entry(dtype, shape, k, len(data[k]), len(raw), _masked(crc))))
+        data[k] += raw
+    for k in range(shards):
+        open("%s.data-%05d-of-%05d" % (prefix, k, shards), "wb").write(data[k])
+    open(prefix + ".index", "wb").write(_hand_table(items, per_block, compress))
+
+
+def _keras_like_checkpoint(g, e):
+    """What tf.train.Checkpoint(g_net=..., e_net=..., g_e_optimizer=...) plausibly writes for two Keras models whose
+    dense layers hang off `all_layers` lists: variable keys spelled the way Keras' own layer tracking would spell them
+    (NOT the all_layers/<i>/0 text), Adam slots, a save counter, and the object graph that ties the code's attribute
+    path to those keys.  Returns (tensors, graph bytes)."""
+    sfx = "/.ATTRIBUTES/VARIABLE_VALUE"
+    tensors, nodes = {}, [dict(children=[], attrs=[], slots=[])]
+
+    def add(parent, name):
+        nodes.append(dict(children=[], attrs=[], slots=[]))
+        nodes[parent]["children"].append((name, len(nodes) - 1))
+        return len(nodes) - 1
+
+    opt = add(0, "g_e_optimizer")
+    ctr = add(0, "save_counter")
+    nodes[ctr]["attrs"].append(("VARIABLE_VALUE", "save_counter", "save_counter" + sfx))
+    tensors["save_counter" + sfx] = np.array(3, dtype=np.int64)
+    for attr, net in (("e_net", e), ("g_net", g)):
+        a = add(0, attr)
+        lst = add(a, "all_layers")
+        for i, (w, b) in enumerate(zip(net.weights, net.biases)):
+            pair = add(lst, str(i))
+            dense = add(pair, "0")
+            nodes[a]["children"].append(("layer_with_weights-%d" % i, dense))        # a second path to the same node
+            norm = add(pair, "1")                                                      # the BatchNormalization twin
+            for var, arr in (("kernel", w), ("bias", b)):
+                key = "%s/layer_with_weights-%d/%s%s" % (attr, i, var, sfx)
+                v = add(dense, var)
+                nodes[v]["attrs"].append(("VARIABLE_VALUE", "%s/dense_%d/%s" % (attr, i, var), key))
+                tensors[key] = arr
+                for slot in ("m", "v"):
+                    sk = "%s/layer_with_weights-%d/%s/.OPTIMIZER_SLOT/g_e_optimizer/%s%s" % (attr, i, var, slot, sfx)
+                    sv = len(nodes)
+                    nodes.append(dict(children=[], attrs=[("VARIABLE_VALUE", "Adam/" + slot, sk)], slots=[]))
+                    nodes[opt]["slots"].append((v, slot, sv))
+                    tensors[sk] = np.zeros_like(arr) + (1 if slot == "m" else 2)
+            nodes[norm]["attrs"].append(("VARIABLE_VALUE", "bn/gamma", "%s/bn%d/gamma%s" % (attr, i, sfx)))
+            tensors["%s/bn%d/gamma%s" % (attr, i, sfx)] = np.ones(w.shape[1], np.float32)
+    graph = b""
+    for nd in nodes:
+        body = b""
+        for name, nid in nd["children"]:
+            body += _ld(1, (b"\x08" + _vi(nid) if nid else b"") + _ld(2, name.encode()))
+        for name, full, key in nd["attrs"]:
+            body += _ld(2, _ld(1, name.encode()) + _ld(2, full.encode()) + _ld(3, key.encode()))
+        for orig, slot, var in nd["slots"]:
+            body += _ld(3, b"\x08" + _vi(orig) + _ld(2, slot.encode()) + b"\x18" + _vi(var))
+        body += _ld(5, b"\x08\x01")                                    # has_checkpoint_values { value: true }
+        graph += _ld(1, body)
+    return tensors, graph
+
+
+def test_reader_on_a_hand_assembled_v2_checkpoint(tmp_path):
+    """PARITY UNPINNED (no TF-written file exists offline).  The reader against an index that write_bundle did not
+    produce: snappy-compressed data blocks, restart interval 16 over 40-entry blocks, two data shards, a DT_STRING
+    object graph, int64 and Adam-slot entries — and variable keys that do NOT have the expected text, so load_v2 can
+    only find the dense layers by walking the object graph along g_net -> all_layers -> i -> 0 -> kernel / bias."""
+    g = BaseFullyConnectedNet(3, 5, "g_net", [24, 16, 24], rng=np.random.RandomState(0))
+    e = BaseFullyConnectedNet(5, 3, "e_net", [8, 8], rng=np.random.RandomState(1))
+    tensors, graph = _keras_like_checkpoint(g, e)
+    tensors["_CHECKPOINTABLE_OBJECT_GRAPH"] = graph
+    prefix = str(tmp_path / "ckpt-3")
+    _hand_bundle(prefix, tensors, shards=2)
+    r = ck.BundleReader(prefix)
+    assert r.num_shards == 2 and len(r.entries) == len(tensors) and len(tensors) > 40
+    assert {r.entries[k]["shard_id"] for k in r.entries} == {0, 1}
+    assert r.get_strings("_CHECKPOINTABLE_OBJECT_GRAPH", verify=True) == [graph]
+    assert int(r.get_tensor("save_counter/.ATTRIBUTES/VARIABLE_VALUE")) == 3
+    nodes = r.object_graph()
+    key = ck.resolve_path(nodes, ["g_net", "all_layers", "2", "0", "kernel"])
+    assert key == "g_net/layer_with_weights-2/kernel/.ATTRIBUTES/VARIABLE_VALUE"
+    assert ck.resolve_path(nodes, ["g_net", "layer_with_weights-2", "bias"]).endswith("-2/bias/.ATTRIBUTES/VARIABLE_VALUE")
+    opt = nodes[nodes[0]["children"]["g_e_optimizer"]]
+    assert len(opt["slots"]) == 2 * 2 * (4 + 3) and opt["slots"][0][1] == "m"
+    g2 = BaseFullyConnectedNet(3, 5, "g_net", [24, 16, 24])
+    e2 = BaseFullyConnectedNet(5, 3, "e_net", [8, 8])
+    ck.load_v2(prefix, g2, e2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(e.get_weights(), e2.get_weights()))
+    with pytest.raises(KeyError):                                       # one dense layer more than the file holds
+        ck.load_v2(prefix, BaseFullyConnectedNet(3, 5, "g_net", [24, 16, 24, 24]), e2)
+    # a flipped byte in a data shard is caught by the per-tensor crc32c (and passes unnoticed only on request)
+    for shard in (0, 1):
+        path = "%s.data-%05d-of-00002" % (prefix, shard)
+        raw = bytearray(open(path, "rb").read())
+        raw[len(raw) // 2] ^= 0x10
+        open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        for k in sorted(tensors):
+            if k != "_CHECKPOINTABLE_OBJECT_GRAPH":
+                r.get_tensor(k)
+    # a flipped byte in a compressed index block is caught by the block checksum
+    raw = bytearray(open(prefix + ".index", "rb").read())
+    raw[100] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        ck.BundleReader(prefix)
+
+
+def test_reader_on_a_hand_assembled_v1_checkpoint(tmp_path):
+    """The tf.train.Saver layout (main_density_est.py:123,389-395) assembled by the independent code above: one shard,
+    uncompressed 7-entry blocks, Adam slots and beta powers beside the variables; load_v1 with its default
+    verify=True, and a corrupted data file is refused."""
+    g = Generator(2, 3, "g_net", 3, 16, rng=np.random.RandomState(2))
+    h = Generator(3, 2, "h_net", 3, 8, rng=np.random.RandomState(3))
+    tensors = {"beta1_power": np.array(0.5, np.float32), "beta2_power": np.array(0.9, np.float32)}
+    for net in (g, h):
+        for (wn, bn), w, b in zip(ck.v1_names(net.name, 4), net.weights, net.biases):
+            for name, arr in ((wn, w), (bn, b)):
+                tensors[name] = arr
+                tensors[name + "/Adam"] = np.zeros_like(arr)
+                tensors[name + "/Adam_1"] = np.ones_like(arr)
+    prefix = str(tmp_path / "model.ckpt-best")
+    _hand_bundle(prefix, tensors, shards=1, per_block=7, compress=False)
+    g2, h2 = Generator(2, 3, "g_net", 3, 16), Generator(3, 2, "h_net", 3, 8)
+    ck.load_v1(prefix, g2, h2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(h.get_weights(), h2.get_weights()))
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    off = ck.BundleReader(prefix).entries["g_net/fully_connected_2/weights"]["offset"]
+    raw[off + 9] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        ck.load_v1(prefix, g2, h2)
+    ck.load_v1(prefix, g2, h2, verify=False)                            # on request the damage passes unnoticed
+    assert not np.array_equal(g2.weights[2], g.weights[2])
+
+
+def test_own_writer_round_trips_object_graph_and_shards(tmp_path):
+    g = BaseFullyConnectedNet(2, 2, "g_net", [16, 16], rng=np.random.RandomState(0))
+    e = BaseFullyConnectedNet(2, 2, "e_net", [8, 8], rng=np.random.RandomState(1))
+    prefix = str(tmp_path / "ckpt-2")
+    ck.save_v2(prefix, g, e, shards=3)
+    assert all(os.path.exists("%s.data-%05d-of-00003" % (prefix, k)) for k in range(3))
+    r = ck.BundleReader(prefix)
+    nodes = r.object_graph()
+    assert ck.resolve_path(nodes, ["e_net", "all_layers", "1", "0", "bias"]) == \
+        "e_net/all_layers/1/0/bias/.ATTRIBUTES/VARIABLE_VALUE"
+    assert r.get_strings(ck.OBJECT_GRAPH_KEY, verify=True)[0] == ck._encode_object_graph(
+        ck.v2_object_graph([("g_net", g), ("e_net", e)]))
+    g2, e2 = BaseFullyConnectedNet(2, 2, "g_net", [16, 16]), BaseFullyConnectedNet(2, 2, "e_net", [8, 8])
+    ck.load_v2(prefix, g2, e2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), g2.get_weights()))
+    assert all(np.array_equal(a, b) for a, b in zip(e.get_weights(), e2.get_weights()))
+
+
+def test_native_crc32c_equals_the_python_one():
+    data = np.random.RandomState(0).bytes(100003)
+    assert ck.crc32c(data) == ck._crc32c_py(data)
+    assert ck.crc32c(data[5000:], ck.crc32c(data[:5000])) == ck._crc32c_py(data)
+    assert _crc32c_bitwise(data[:3000]) == ck._crc32c_py(data[:3000])
+    lib = _lib.load()
+    assert lib.rt_crc32c(b"123456789", 9, 0) == 0xE3069283
+
+
 def test_latest_checkpoint(tmp_path):
     assert ck.latest_checkpoint(str(tmp_path)) is None
     ck.write_checkpoint_state(str(tmp_path), "ckpt-9")
