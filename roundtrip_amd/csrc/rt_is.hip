@@ -67,6 +67,7 @@ struct HostMlp {
     int n_layers = 0;
     int hid = 0;              // hidden width the kernels run at: max hidden width padded up to 128/256/512/1024
     int nst = 2;              // sample tiles per wave (2: 64 samples per pass; 1: 32, for width 1024)
+    int nw = 4;               // waves per workgroup (rt_mlp.hpp): 1 for narrow nets (width <= 128, small in / out dims)
     std::vector<int> dims;
     std::vector<void*> dev;   // device allocations to free
     MlpArgs args;
@@ -178,36 +179,39 @@ hipError_t allow_lds(rt_ctx* ctx, const void* fn, int lds) {
     return e;
 }
 
-template <int HID, int NST, bool GIVEN, bool SHARE>
+template <int HID, int NST, bool GIVEN, bool SHARE, int NW>
 int launch_is_variant(rt_ctx* ctx, const IsArgs& a, int grid, int lds) {
-    HIPCHK(ctx, allow_lds(ctx, (const void*)is_fused_kernel<HID, NST, GIVEN, SHARE>, lds));
-    hipLaunchKernelGGL((is_fused_kernel<HID, NST, GIVEN, SHARE>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, a);
+    HIPCHK(ctx, allow_lds(ctx, (const void*)is_fused_kernel<HID, NST, GIVEN, SHARE, NW>, lds));
+    hipLaunchKernelGGL((is_fused_kernel<HID, NST, GIVEN, SHARE, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
 
-template <int HID, int NST>
+template <int HID, int NST, int NW = 4>
 int launch_is(rt_ctx* ctx, const IsArgs& a, bool given, int grid, int lds) {
-    if (given) return launch_is_variant<HID, NST, true, false>(ctx, a, grid, lds);
+    if (given) return launch_is_variant<HID, NST, true, false, NW>(ctx, a, grid, lds);
     // more than one Philox call per sample (4 normals each: df of them for chi2, then the dx coordinates; the gamma path
-    // of a non-integer df draws its chi2 apart): the threads of a sample slot share the calls
-    const bool share = a.sa.ndf + a.g.in_dim > 4;
-    return share ? launch_is_variant<HID, NST, false, true>(ctx, a, grid, lds)
-                 : launch_is_variant<HID, NST, false, false>(ctx, a, grid, lds);
+    // of a non-integer df draws its chi2 apart): the threads of a sample slot share the calls.  (A one-wave workgroup
+    // has one thread per sample: nothing to share.)
+    const bool share = NW > 1 && a.sa.ndf + a.g.in_dim > 4;
+    if constexpr (NW > 1) {
+        if (share) return launch_is_variant<HID, NST, false, true, NW>(ctx, a, grid, lds);
+    }
+    return launch_is_variant<HID, NST, false, false, NW>(ctx, a, grid, lds);
 }
 
-template <int HID, int NST>
+template <int HID, int NST, int NW = 4>
 int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* out, int grid, int lds) {
-    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_fwd_kernel<HID, NST>, lds));
-    hipLaunchKernelGGL((mlp_fwd_kernel<HID, NST>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, out);
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_fwd_kernel<HID, NST, NW>, lds));
+    hipLaunchKernelGGL((mlp_fwd_kernel<HID, NST, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, m, in, N, out);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
 
-template <int HID>
+template <int HID, int NW = 4>
 int launch_jvp(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
-    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_kernel<HID>, lds));
-    hipLaunchKernelGGL((mlp_jvp_kernel<HID>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, m, in, N, yout, J);
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_kernel<HID, NW>, lds));
+    hipLaunchKernelGGL((mlp_jvp_kernel<HID, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, m, in, N, yout, J);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -272,7 +276,7 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     const int nst = G.nst;
     const int MS = 32 * nst;
-    const int grid_max = ctx->cu_count;
+    const int grid_max = ctx->cu_count * (G.nw == 1 ? 4 : 1);   // one-wave workgroups: four per CU, one per SIMD
     const IsPlan pl = is_plan(N, S, nst);
     if (e_hi < 0) e_hi = pl.E;
     // main entries of the range, and whether the leftover entry (the last one, E - 1, in packed mode) is in it
@@ -300,7 +304,7 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
     a.inv_df = 1.0 / df;
     a.half_dfp1 = 0.5 * (df + 1.0);
 
-    const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy);
+    const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy, 64 * G.nw);
     const int grid = (int)((a.p_total < grid_max) ? a.p_total : grid_max);
     if (pb.timed) {
         if (ctx->events_used == MAX_EVENT_PAIRS) {
@@ -316,7 +320,12 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used].first, ctx->stream));
     }
     const bool given = xs != nullptr;
-    switch (G.hid * 10 + nst) {
+    // one-wave workgroups ask for more than a fifth of the LDS, so that at most four share a CU (one per SIMD) however
+    // few registers and however little LDS they need
+    const int lds1 = cv.total > 33 * 1024 ? cv.total : 33 * 1024;
+    switch (G.hid * 10 + nst + (G.nw == 1 ? 100000 : 0)) {
+        case 100642: rc = launch_is<64, 2, 1>(ctx, a, given, grid, lds1); break;
+        case 101282: rc = launch_is<128, 2, 1>(ctx, a, given, grid, lds1); break;
         case 1282: rc = launch_is<128, 2>(ctx, a, given, grid, cv.total); break;
         case 2562: rc = launch_is<256, 2>(ctx, a, given, grid, cv.total); break;
         case 5122: rc = launch_is<512, 2>(ctx, a, given, grid, cv.total); break;
@@ -406,10 +415,14 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
     if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
     if (N == 0) return RT_OK;
     const int ms = 32 * M.nst;
-    const Carve cv = carve_for(M.hid, ms, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const Carve cv = carve_for(M.hid, ms, M.args.k0, M.args.in_dim, M.args.out_dim, 64 * M.nw);
     const int64_t npass = (N + ms - 1) / ms;
-    const int64_t gmax = (int64_t)ctx->cu_count * 2;
+    const int64_t gmax = (int64_t)ctx->cu_count * (M.nw == 1 ? 4 : 2);
     const int grid = (int)(npass < gmax ? npass : gmax);
+    if (M.nw == 1) {
+        if (M.hid == 64) return launch_fwd<64, 2, 1>(ctx, M.args, in, N, out, grid, cv.total);
+        return launch_fwd<128, 2, 1>(ctx, M.args, in, N, out, grid, cv.total);
+    }
     switch (M.hid) {
         case 128: return launch_fwd<128, 2>(ctx, M.args, in, N, out, grid, cv.total);
         case 256: return launch_fwd<256, 2>(ctx, M.args, in, N, out, grid, cv.total);
@@ -426,10 +439,14 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
     if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
     if (N == 0) return RT_OK;
     if (M.nst != 2) return fail(ctx, RT_EUNSUPPORTED, "Jacobian needs hidden width <= 512 (64-column passes)");
-    const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim);
+    const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim, 64 * M.nw);
     const int64_t npass = ((N + 31) / 32) * M.args.in_dim;
-    const int64_t gmax = (int64_t)ctx->cu_count * 2;
+    const int64_t gmax = (int64_t)ctx->cu_count * (M.nw == 1 ? 4 : 2);
     const int grid = (int)(npass < gmax ? npass : gmax);
+    if (M.nw == 1) {
+        if (M.hid == 64) return launch_jvp<64, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
+        return launch_jvp<128, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
+    }
     switch (M.hid) {
         case 128: return launch_jvp<128>(ctx, M.args, in, N, yout, J, grid, cv.total);
         case 256: return launch_jvp<256>(ctx, M.args, in, N, yout, J, grid, cv.total);
@@ -512,12 +529,25 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     int hmax = 0;
     for (int l = 1; l < n_layers; ++l) if (dims[l] > hmax) hmax = dims[l];
     if (hmax > 1024) return fail(ctx, RT_EUNSUPPORTED, "hidden width > 1024");
-    // the kernels run at one of four widths; narrower / unequal hidden layers are zero-padded up (exact)
-    const int hid = hmax <= 128 ? 128 : hmax <= 256 ? 256 : hmax <= 512 ? 512 : 1024;
+    // the kernels run at one of five widths; narrower / unequal hidden layers are zero-padded up (exact)
+    int hid = hmax <= 128 ? 128 : hmax <= 256 ? 256 : hmax <= 512 ? 512 : 1024;
     const int nst = hid == 1024 ? 1 : 2;
     if (dims[0] > MAX_IN) return fail(ctx, RT_EUNSUPPORTED, "input dim > 128");
     if (dims[n_layers] > MAX_OUT) return fail(ctx, RT_EUNSUPPORTED, "output dim > 128");
-    if (carve_for(hid, 32 * nst, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers]).total > LDS_MAX)
+    // narrow nets run as one-wave workgroups, four to a CU (rt_mlp.hpp, NW = 1), at width 64 or 128: needs the output
+    // layer in one 32-feature tile and a quarter of the LDS (40 KiB) per workgroup.  RT_IS_NARROW=0 (read here) keeps
+    // them on the four-wave kernel, zero-padded to width 128 — the same bits, for A/B timing.
+    int nw = 4;
+    if (hmax <= 128 && dims[n_layers] <= 32) {
+        const int h1 = hmax <= 64 ? 64 : 128;
+        const char* env = getenv("RT_IS_NARROW");
+        if (!(env && env[0] == '0') &&
+            carve_for(h1, 64, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64).total <= LDS_MAX / 4) {
+            nw = 1;
+            hid = h1;
+        }
+    }
+    if (carve_for(hid, 32 * nst, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64 * nw).total > LDS_MAX)
         return fail(ctx, RT_EUNSUPPORTED, "input dim too large for this hidden width (LDS budget of 160 KiB)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -526,6 +556,7 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     M.n_layers = n_layers;
     M.hid = hid;
     M.nst = nst;
+    M.nw = nw;
     M.dims.assign(dims, dims + n_layers + 1);
     memset(&M.args, 0, sizeof(M.args));
     M.args.n_layers = n_layers;

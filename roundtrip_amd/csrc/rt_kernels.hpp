@@ -46,7 +46,7 @@ struct Carve {
     int x0, act, scr, yb, xh, total;
 };
 
-__host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim) {
+__host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim, int nthreads = NTHREADS) {
     Carve c;
     int off = 0;
     c.x0 = off; off += k0 * ms * 4;
@@ -54,7 +54,7 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     const int part_bytes = 4 * out_dim * ms * 4;
     if (part_bytes > act_bytes) act_bytes = part_bytes;
     c.act = off; off += act_bytes;
-    c.scr = off; off += 2 * NTHREADS * 8;            // per (phase, sample): squared error, log weight
+    c.scr = off; off += 2 * nthreads * 8;            // per (phase, sample): squared error, log weight
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
     c.total = off;
@@ -104,14 +104,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 // SHARE: the NP threads of a sample slot share the sample's Philox calls (chosen by the host when a sample takes more
 // than one call, dx + df > 4); otherwise one thread draws the whole sample.  Same values either way (see draw_sample); a
 // separate instantiation because the register allocation of the one-call kernel — the 2-D sets, the bench — is kept as is.
-template <int HID, int NST, bool GIVEN, bool SHARE = false>
-__global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
+// NW = 1 (rt_mlp.hpp): the workgroup is one wave; grid = 4 per CU.
+template <int HID, int NST, bool GIVEN, bool SHARE = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
+    constexpr int NTHREADS = 64 * NW;     // (shadows the namespace-scope default of 256)
     constexpr int MS = 32 * NST;          // samples per pass
     constexpr int NP = NTHREADS / MS;     // threads per sample in the scoring phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MlpArgs& m = a.g;
     const int dx = m.in_dim, dy = m.out_dim;
-    const Carve cv = carve_for(HID, MS, m.k0, dx, dy);
+    const Carve cv = carve_for(HID, MS, m.k0, dx, dy, NTHREADS);
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     double* scr = (double*)(smem + cv.scr);
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
             __syncthreads();
         }
         ST(7)
-        MlpPre<HID> pre;
-        mlp_prefetch<HID, NST>(m, pre, wave, lane);
+        MlpPre<HID, NW> pre;
+        mlp_prefetch<HID, NST, false, NW>(m, pre, wave, lane);
         // ---- A. proposal samples -> x0 image --------------------------------------------------
         {
             const Slot sl = slot_of(s);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS) void is_fused_kernel(const IsArgs a) {
         __syncthreads();
         ST(0)
         // ---- B. G forward ---------------------------------------------------------------------
-        mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
+        mlp_core<HID, NST, false, NW>(m, pre, x0, act, wave, lane ST_ARG);
         // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
         int s2 = s;
         asm volatile("" : "+v"(s2));
@@ -302,13 +304,14 @@ __global__ __launch_bounds__(256) void is_finalize_kernel(const double* partial,
 // ----------------------------------------------------------------------------------------------
 // Plain MLP forward (predict_x / predict_y): 32*NST rows per pass.
 // ----------------------------------------------------------------------------------------------
-template <int HID, int NST>
-__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, const float* in, int64_t N,
-                                                           float* out) {
+template <int HID, int NST, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                          float* out) {
+    constexpr int NTHREADS = 64 * NW;
     constexpr int MS = 32 * NST;
     constexpr int NP = NTHREADS / MS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim);
+    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim, NTHREADS);
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     const float* part = (const float*)act;
@@ -328,9 +331,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
 #ifdef RT_STAMPS
         Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
-        MlpPre<HID> pre;
-        mlp_prefetch<HID, NST>(m, pre, wave, lane);
-        mlp_core<HID, NST>(m, pre, x0, act, wave, lane ST_ARG);
+        MlpPre<HID, NW> pre;
+        mlp_prefetch<HID, NST, false, NW>(m, pre, wave, lane);
+        mlp_core<HID, NST, false, NW>(m, pre, x0, act, wave, lane ST_ARG);
         if (row < N)
             for (int d = ph; d < m.out_dim; d += NP) out[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
     }
@@ -344,12 +347,13 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpArgs m, cons
 // The primal is recomputed for every d (in_dim x the work of a plain forward; this path runs once per QUERY
 // POINT, not per sample, so it is ~1e-4 of the IS estimate's work).
 // ----------------------------------------------------------------------------------------------
-template <int HID>
-__global__ __launch_bounds__(NTHREADS) void mlp_jvp_kernel(const MlpArgs m, const float* in, int64_t N,
-                                                           float* yout, float* J) {
+template <int HID, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                          float* yout, float* J) {
+    constexpr int NTHREADS = 64 * NW;
     constexpr int MS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim);
+    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim, NTHREADS);
     char* x0 = smem + cv.x0;
     char* act = smem + cv.act;
     const float* part = (const float*)act;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_jvp_kernel(const MlpArgs m, cons
         const int dir = (int)(ps - blk * m.in_dim);
         const int64_t row = blk * 32 + (sl & 31);
         __syncthreads();
-        for (int d = ph; d < m.in_dim; d += 4) {
+        for (int d = ph; d < m.in_dim; d += NW) {
             float v;
             if (sl < 32) v = (row < N) ? in[row * m.in_dim + d] : 0.0f;
             else v = (d == dir) ? 1.0f : 0.0f;
@@ -374,14 +378,14 @@ __global__ __launch_bounds__(NTHREADS) void mlp_jvp_kernel(const MlpArgs m, cons
 #ifdef RT_STAMPS
         Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
-        MlpPre<HID> pre;
-        mlp_core<HID, 2, true>(m, pre, x0, act, wave, lane ST_ARG);
+        MlpPre<HID, NW> pre;
+        mlp_core<HID, 2, true, NW>(m, pre, x0, act, wave, lane ST_ARG);
         if (row < N) {
             if (sl < 32) {
                 if (dir == 0 && yout)
-                    for (int d = ph; d < m.out_dim; d += 4) yout[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
+                    for (int d = ph; d < m.out_dim; d += NW) yout[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
             } else {
-                for (int d = ph; d < m.out_dim; d += 4)
+                for (int d = ph; d < m.out_dim; d += NW)
                     J[(row * m.out_dim + d) * m.in_dim + dir] = mlp_out_nobias<MS>(m, part, d, sl);
             }
         }

@@ -4,7 +4,12 @@
 #pragma once
 
 
-constexpr int NTHREADS = 256;   // 4 waves, one per SIMD
+constexpr int NTHREADS = 256;   // 4 waves, one per SIMD (NW = 4, the default of every template below)
+// NW = waves per workgroup.  NW = 4: a workgroup per CU, the hidden layer's features split over its four waves, barriers
+// between the layer stages.  NW = 1 (hidden width <= 128, see rt_set_mlp): a workgroup is ONE wave that owns all features
+// of its own 64 samples — four of them share a CU, one per SIMD; there is nothing to synchronise with, so hipcc drops the
+// s_barrier of every __syncthreads() (the LDS fence stays) and the per-pass sampler / scorer / reduction, which run on
+// one wave per workgroup, keep all four SIMDs busy instead of one.  Same arithmetic in the same order: bit-identical.
 constexpr int MAX_IN = 128;     // max input dim of a fused MLP (also bounded by the LDS budget)
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int MAX_OUT = 128;    // max output dim of a fused MLP (dy for G)
@@ -581,14 +586,14 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
 // Operands of a pass that do not depend on its samples — layer 0's bias (straight into both tiles' accumulators) and
 // its first weights — requested BEFORE the pass's samples are drawn, so that their round trip (they have been evicted
 // from L2 by the 9 MB of weights streamed since the previous pass) hides behind the sampler.
-template <int HID>
+template <int HID, int NW = 4>
 struct MlpPre {
-    f32x16 acc[HID / 128][2];
-    f32x4 a[HID / 128];
+    f32x16 acc[HID / (32 * NW)][2];
+    f32x4 a[HID / (32 * NW)];
 };
-template <int HID>
-__device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID>& pre, int wave, int lane) {
-    constexpr int NFT = HID / 128, FTT = HID / 32;
+template <int HID, int NW = 4>
+__device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
+    constexpr int NFT = HID / (32 * NW), FTT = HID / 32;
     const BiasSrc b0 = make_bias(m.bp[0], (32 * wave * NFT + 4 * (lane >> 5)) * 4);
     const WSrc w0 = make_wsrc(m.wp[0] + (wave * NFT) * 256, lane);
 #pragma unroll
@@ -602,10 +607,10 @@ __device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID>& pre
 // closing barrier still to come (the caller requests the output layer's weights first).
 // Layer 0 (K = k0, a few k-groups) is the same dance without the skew: all k-groups but the last for both tiles, then
 // the last one: tile A's MFMAs, A's leaky-ReLU cluster, tile B's MFMAs with A's stores behind them, barrier, B's cluster.
-template <int HID>
-__device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID>& pre, const char* x0, char* act, int wave,
+template <int HID, int NW = 4>
+__device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>& pre, const char* x0, char* act, int wave,
                                               int lane ST_PARAM) {
-    constexpr int NFT = HID / 128, FTT = HID / 32, NKG = HID / 8;
+    constexpr int NFT = HID / (32 * NW), FTT = HID / 32, NKG = HID / 8;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
     const int nkg0 = m.k0 >> 3;
@@ -711,31 +716,78 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
 // k ascends.  wsmall[((kg*2 + hh)*4 + i)*4 + e] = W[8kg + 4hh + e][i] (zero for i >= out_dim).
 // small_load_w requests this wave's K-quarter of the weights (they do not depend on the activations: it is called
 // before the barrier that publishes the last hidden layer, so the L2 round trip hides behind it).
-template <int KQ>
-__device__ __forceinline__ void small_load_w(const MlpArgs& m, int wave, int lane, f32x4 (&w)[2 * KQ]) {
+// NQL = K-quarters this wave computes, starting at quarter `wave` (NW = 4: its own one; NW = 1: all the non-empty
+// quarters of the 128-wide net the oracle's summation order is defined on, one accumulator chain each; the empty
+// quarters of a 64-wide net contribute the +0 they contribute in the zero-padded 128-wide kernel).
+template <int KQ, int NQL = 1>
+__device__ __forceinline__ void small_load_w(const MlpArgs& m, int wave, int lane, f32x4 (&w)[2 * KQ * NQL]) {
     const f32x4* wp = (const f32x4*)m.wsmall + (size_t)(wave * KQ) * 8 + (lane & 3);
 #pragma unroll
-    for (int i = 0; i < 2 * KQ; ++i) w[i] = wp[i * 4];
+    for (int i = 0; i < 2 * KQ * NQL; ++i) w[i] = wp[i * 4];
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KQ>
-__device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (&w)[2 * KQ], char* act, float* part,
+template <int KQ, int NQL = 1>
+__device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (&w)[2 * KQ * NQL], char* act, float* part,
                                                  int wave, int lane) {
     constexpr int MS = 64;
-    f32x4 b[2 * KQ];
+    f32x4 b[2 * KQ * NQL];
 #pragma unroll
-    for (int i = 0; i < 2 * KQ; ++i) b[i] = *(const f32x4*)(act + act_off<MS>(wave * KQ + (i >> 1), lane, i & 1));
+    for (int i = 0; i < 2 * KQ * NQL; ++i) b[i] = *(const f32x4*)(act + act_off<MS>(wave * KQ + (i >> 1), lane, i & 1));
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NQL];
 #pragma unroll
-    for (int i = 0; i < 2 * KQ; ++i)
+    for (int q = 0; q < NQL; ++q) {
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i][e], b[i][e], acc, 0, 0, 0);
+        for (int i = 2 * KQ * q; i < 2 * KQ * (q + 1); ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i][e], b[i][e], acc[q], 0, 0, 0);
+    }
     __syncthreads();   // every wave is done reading the activation image
     const int od = m.out_dim;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-        if (d < od) part[(wave * od + d) * MS + lane] = acc[d];
+    for (int q = 0; q < NQL; ++q)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < od) part[((wave + q) * od + d) * MS + lane] = acc[q][d];
+    if constexpr (NQL > 1 && NQL < 4) {
+#pragma unroll
+        for (int q = NQL; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < od) part[(q * od + d) * MS + lane] = 0.0f;
+    }
+    __syncthreads();
+}
+
+// Output layer of a one-wave workgroup (NW = 1), out_dim <= 32: the NQL non-empty K-quarters one after the other, each
+// its own accumulator chain on a 32-feature tile x 2 sample tiles, all kept in registers until every operand has been
+// read (part aliases the activation image); quarters NQL..3 are written as +0.
+template <int NQL>
+__device__ __forceinline__ void last_layer_one_wave(const MlpArgs& m, char* act, float* part, int lane) {
+    constexpr int MS = 64, KQ = 4;
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[NQL][1][2];
+#pragma unroll
+    for (int q = 0; q < NQL; ++q) {
+        const WSrc wl = make_wsrc(m.wp[m.n_layers - 1] + (size_t)(q * KQ) * 256, lane);
+        f32x4 a0[1], a1[1], a2[1];
+        prefetch_a<1>(a0, a1, a2, wl, 64);
+        gemm_tile<1, 2>(acc[q], a0, a1, a2, wl, 1, KQ, act + act_off<MS>(q * KQ, j, h), nullptr);
+    }
+    __syncthreads();   // (one wave: an LDS fence) every operand has been read
+    const int od = m.out_dim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (d < od) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    part[(q * od + d) * MS + 32 * st + j] = (q < NQL) ? acc[q < NQL ? q : 0][0][st][r] : 0.0f;
+        }
+    }
     __syncthreads();
 }
 
@@ -746,27 +798,32 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
 template <int HID, int NST, bool JVP = false>
 constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 128, 256, 512
 
-template <int HID, int NST, bool JVP = false>
-__device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID>& pre, int wave, int lane) {
-    if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID>(m, pre, wave, lane);
+template <int HID, int NST, bool JVP = false, int NW = 4>
+__device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
+    if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID, NW>(m, pre, wave, lane);
 }
 
-template <int HID, int NST, bool JVP = false>
-__device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID>& pre, char* x0, char* act, int wave,
+template <int HID, int NST, bool JVP = false, int NW = 4>
+__device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre, char* x0, char* act, int wave,
                                          int lane ST_PARAM) {
-    constexpr int NFT = HID / 128;
+    static_assert(NW == 4 || (NW == 1 && NST == 2 && HID <= 128), "one-wave workgroups: 64-sample passes, width <= 128");
+    constexpr int NFT = HID / (32 * NW);
     constexpr int FTT = HID / 32;
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
-    constexpr int KQ = HID / 32;        // k-groups per wave in the output layer
+    // the output layer's K is split into four quarters whose partial sums are added ((p0+p1)+p2)+p3.  NW = 4: a wave
+    // per quarter, HID/32 k-groups each.  NW = 1: the quarters are those of the 128-wide net (4 k-groups each, as in
+    // the zero-padded 128-wide kernel and in the oracle's kernel order), of which HID/32 are not empty.
+    constexpr int KQ = (NW == 4) ? HID / 32 : 4;
+    constexpr int NQL = (NW == 4) ? 1 : HID / 32;
     const bool small_out = (NST == 2) && m.wsmall != nullptr;
-    f32x4 wsm[2 * KQ];
+    f32x4 wsm[2 * KQ * NQL];
     constexpr bool SKEWED = mlp_is_skewed<HID, NST, JVP>();
     if constexpr (SKEWED) {
-        hidden_skewed<HID>(m, pre, x0, act, wave, lane ST_ARG);
+        hidden_skewed<HID, NW>(m, pre, x0, act, wave, lane ST_ARG);
         ST(1)
-        if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
+        if (small_out) small_load_w<KQ, NQL>(m, wave, lane, wsm);
         __syncthreads();
         ST(1)
     } else {
@@ -803,14 +860,19 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID>& pre, cha
         if (nhid > 1) __syncthreads();
         ST(2)
         store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
-        if (small_out) small_load_w<KQ>(m, wave, lane, wsm);
+        if (small_out) small_load_w<KQ, NQL>(m, wave, lane, wsm);
         ST(3)
         __syncthreads();
         ST(4)
     }
     float* part = (float*)act;
     if (small_out) {
-        last_layer_small<KQ>(m, wsm, act, part, wave, lane);
+        last_layer_small<KQ, NQL>(m, wsm, act, part, wave, lane);
+        ST(6)
+        return;
+    }
+    if constexpr (NW == 1) {
+        last_layer_one_wave<NQL>(m, act, part, lane);   // out_dim <= 32 (rt_set_mlp)
         ST(6)
         return;
     }
