@@ -276,7 +276,7 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
     const int dx = G.args.in_dim, dy = G.args.out_dim;
     const int nst = G.nst;
     const int MS = 32 * nst;
-    const int grid_max = ctx->cu_count * (G.nw == 1 ? 4 : 1);   // one-wave workgroups: four per CU, one per SIMD
+    const int grid_max = ctx->cu_count * (4 / G.nw);   // one- / two-wave workgroups: four / two per CU, a wave per SIMD
     const IsPlan pl = is_plan(N, S, nst);
     if (e_hi < 0) e_hi = pl.E;
     // main entries of the range, and whether the leftover entry (the last one, E - 1, in packed mode) is in it
@@ -320,12 +320,14 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used].first, ctx->stream));
     }
     const bool given = xs != nullptr;
-    // one-wave workgroups ask for more than a fifth of the LDS, so that at most four share a CU (one per SIMD) however
-    // few registers and however little LDS they need
+    // one-wave (two-wave) workgroups ask for more than a fifth (a third) of the LDS, so that at most four (two) share a
+    // CU — a wave per SIMD — however few registers and however little LDS they need
     const int lds1 = cv.total > 33 * 1024 ? cv.total : 33 * 1024;
-    switch (G.hid * 10 + nst + (G.nw == 1 ? 100000 : 0)) {
+    const int lds2 = cv.total > 54 * 1024 ? cv.total : 54 * 1024;
+    switch (G.hid * 10 + nst + (G.nw != 4 ? 100000 * G.nw : 0)) {
         case 100642: rc = launch_is<64, 2, 1>(ctx, a, given, grid, lds1); break;
         case 101282: rc = launch_is<128, 2, 1>(ctx, a, given, grid, lds1); break;
+        case 202562: rc = launch_is<256, 2, 2>(ctx, a, given, grid, lds2); break;
         case 1282: rc = launch_is<128, 2>(ctx, a, given, grid, cv.total); break;
         case 2562: rc = launch_is<256, 2>(ctx, a, given, grid, cv.total); break;
         case 5122: rc = launch_is<512, 2>(ctx, a, given, grid, cv.total); break;
@@ -423,6 +425,7 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
         if (M.hid == 64) return launch_fwd<64, 2, 1>(ctx, M.args, in, N, out, grid, cv.total);
         return launch_fwd<128, 2, 1>(ctx, M.args, in, N, out, grid, cv.total);
     }
+    if (M.nw == 2) return launch_fwd<256, 2, 2>(ctx, M.args, in, N, out, grid, cv.total);
     switch (M.hid) {
         case 128: return launch_fwd<128, 2>(ctx, M.args, in, N, out, grid, cv.total);
         case 256: return launch_fwd<256, 2>(ctx, M.args, in, N, out, grid, cv.total);
@@ -447,6 +450,7 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
         if (M.hid == 64) return launch_jvp<64, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
         return launch_jvp<128, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
     }
+    if (M.nw == 2) return launch_jvp<256, 2>(ctx, M.args, in, N, yout, J, grid, cv.total);
     switch (M.hid) {
         case 128: return launch_jvp<128>(ctx, M.args, in, N, yout, J, grid, cv.total);
         case 256: return launch_jvp<256>(ctx, M.args, in, N, yout, J, grid, cv.total);
@@ -537,13 +541,15 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
     // narrow nets run as one-wave workgroups, four to a CU (rt_mlp.hpp, NW = 1), at width 64 or 128: needs the output
     // layer in one 32-feature tile and a quarter of the LDS (40 KiB) per workgroup.  RT_IS_NARROW=0 (read here) keeps
     // them on the four-wave kernel, zero-padded to width 128 — the same bits, for A/B timing.
+    // Width 256 likewise as two-wave workgroups, two to a CU (half the LDS each).
     int nw = 4;
-    if (hmax <= 128 && dims[n_layers] <= 32) {
-        const int h1 = hmax <= 64 ? 64 : 128;
+    if (hmax <= 256 && dims[n_layers] <= 32) {
+        const int h1 = hmax <= 64 ? 64 : hmax <= 128 ? 128 : 256;
+        const int nw1 = h1 == 256 ? 2 : 1;
         const char* env = getenv("RT_IS_NARROW");
         if (!(env && env[0] == '0') &&
-            carve_for(h1, 64, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64).total <= LDS_MAX / 4) {
-            nw = 1;
+            carve_for(h1, 64, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64 * nw1).total <= LDS_MAX / (4 / nw1)) {
+            nw = nw1;
             hid = h1;
         }
     }

@@ -43,7 +43,7 @@ struct IsArgs {
 };
 
 struct Carve {
-    int x0, act, scr, yb, xh, total;
+    int x0, act, scr, yb, xh, ob, total;
 };
 
 __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, int out_dim, int nthreads = NTHREADS) {
@@ -57,6 +57,7 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     c.scr = off; off += 2 * nthreads * 8;            // per (phase, sample): squared error, log weight
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
+    c.ob = off; off += ((out_dim * 4 + 15) / 16) * 16;   // the output layer's bias, for the scorer (SHARE kernels)
     c.total = off;
     return c;
 }
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
     double* scr = (double*)(smem + cv.scr);
     double* yb = (double*)(smem + cv.yb);
     float* xh = (float*)(smem + cv.xh);
+    float* ob = (float*)(smem + cv.ob);
     const float* part = (const float*)act;
 
     const int tid = threadIdx.x;
@@ -128,6 +130,10 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
 
     // zero the padded rows of the x0 image once: rows >= dx are never written again
     for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // many-dimensional sets (the SHARE kernels: YearPredictionMSD 20/90, ...): the scorer reads the output layer's bias
+    // once per output dim and thread; from LDS that is a broadcast read next to the partial sums, from global memory a
+    // round trip per dim
+    if (SHARE) for (int d = tid; d < dy; d += NTHREADS) ob[d] = m.bp[m.n_layers - 1][d];
     // orders the zero-fill against the first pass's put_x0 writes to the same words: a workgroup whose first pass is a
     // leftover pass (p_main == 0, a pair range of only the last entry, p_main < grid) meets no other barrier before them
     __syncthreads();
@@ -207,7 +213,8 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
         double se = 0.0, lw = 0.0;
         auto score = [&](const auto* yrow, const auto* centre) __attribute__((always_inline)) {
             for (int d = p; d < dy; d += NP) {
-                const double diff = (double)yrow[d] - (double)mlp_out<MS>(m, part, d, s);
+                const float g_d = SHARE ? mlp_out_nobias<MS>(m, part, d, s) + ob[d] : mlp_out<MS>(m, part, d, s);
+                const double diff = (double)yrow[d] - (double)g_d;
                 se += diff * diff;
             }
             for (int d = p; d < dx; d += NP) {

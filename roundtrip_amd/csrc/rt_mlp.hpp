@@ -9,7 +9,9 @@ constexpr int NTHREADS = 256;   // 4 waves, one per SIMD (NW = 4, the default of
 // between the layer stages.  NW = 1 (hidden width <= 128, see rt_set_mlp): a workgroup is ONE wave that owns all features
 // of its own 64 samples — four of them share a CU, one per SIMD; there is nothing to synchronise with, so hipcc drops the
 // s_barrier of every __syncthreads() (the LDS fence stays) and the per-pass sampler / scorer / reduction, which run on
-// one wave per workgroup, keep all four SIMDs busy instead of one.  Same arithmetic in the same order: bit-identical.
+// one wave per workgroup, keep all four SIMDs busy instead of one.  NW = 2 (width 256): two waves with 128 features each,
+// two workgroups to a CU — one SIMD in two idles during a workgroup's serial phases instead of three in four.
+// Same arithmetic in the same order in every case: bit-identical results.
 constexpr int MAX_IN = 128;     // max input dim of a fused MLP (also bounded by the LDS budget)
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int MAX_OUT = 128;    // max output dim of a fused MLP (dy for G)
@@ -716,23 +718,23 @@ __device__ __forceinline__ void last_layer(const MlpArgs& m, int kq, char* act, 
 // k ascends.  wsmall[((kg*2 + hh)*4 + i)*4 + e] = W[8kg + 4hh + e][i] (zero for i >= out_dim).
 // small_load_w requests this wave's K-quarter of the weights (they do not depend on the activations: it is called
 // before the barrier that publishes the last hidden layer, so the L2 round trip hides behind it).
-// NQL = K-quarters this wave computes, starting at quarter `wave` (NW = 4: its own one; NW = 1: all the non-empty
-// quarters of the 128-wide net the oracle's summation order is defined on, one accumulator chain each; the empty
-// quarters of a 64-wide net contribute the +0 they contribute in the zero-padded 128-wide kernel).
+// A wave computes the NQW = 4 / NW quarters q0 .. q0 + NQW - 1 (q0 = wave * NQW), one accumulator chain each; NQL of them
+// are not empty (all, except at width 64, whose sum is defined on the quarters of the 128-wide net: its last two
+// contribute the +0 they contribute in the zero-padded 128-wide kernel).
 template <int KQ, int NQL = 1>
-__device__ __forceinline__ void small_load_w(const MlpArgs& m, int wave, int lane, f32x4 (&w)[2 * KQ * NQL]) {
-    const f32x4* wp = (const f32x4*)m.wsmall + (size_t)(wave * KQ) * 8 + (lane & 3);
+__device__ __forceinline__ void small_load_w(const MlpArgs& m, int q0, int lane, f32x4 (&w)[2 * KQ * NQL]) {
+    const f32x4* wp = (const f32x4*)m.wsmall + (size_t)(q0 * KQ) * 8 + (lane & 3);
 #pragma unroll
     for (int i = 0; i < 2 * KQ * NQL; ++i) w[i] = wp[i * 4];
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KQ, int NQL = 1>
+template <int KQ, int NQL = 1, int NQW = NQL>
 __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (&w)[2 * KQ * NQL], char* act, float* part,
-                                                 int wave, int lane) {
+                                                 int q0, int lane) {
     constexpr int MS = 64;
     f32x4 b[2 * KQ * NQL];
 #pragma unroll
-    for (int i = 0; i < 2 * KQ * NQL; ++i) b[i] = *(const f32x4*)(act + act_off<MS>(wave * KQ + (i >> 1), lane, i & 1));
+    for (int i = 0; i < 2 * KQ * NQL; ++i) b[i] = *(const f32x4*)(act + act_off<MS>(q0 * KQ + (i >> 1), lane, i & 1));
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[NQL];
 #pragma unroll
@@ -749,43 +751,43 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
     for (int q = 0; q < NQL; ++q)
 #pragma unroll
         for (int d = 0; d < 4; ++d)
-            if (d < od) part[((wave + q) * od + d) * MS + lane] = acc[q][d];
-    if constexpr (NQL > 1 && NQL < 4) {
+            if (d < od) part[((q0 + q) * od + d) * MS + lane] = acc[q][d];
+    if constexpr (NQL < NQW) {
 #pragma unroll
-        for (int q = NQL; q < 4; ++q)
+        for (int q = NQL; q < NQW; ++q)
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                if (d < od) part[(q * od + d) * MS + lane] = 0.0f;
+                if (d < od) part[((q0 + q) * od + d) * MS + lane] = 0.0f;
     }
     __syncthreads();
 }
 
-// Output layer of a one-wave workgroup (NW = 1), out_dim <= 32: the NQL non-empty K-quarters one after the other, each
-// its own accumulator chain on a 32-feature tile x 2 sample tiles, all kept in registers until every operand has been
-// read (part aliases the activation image); quarters NQL..3 are written as +0.
-template <int NQL>
-__device__ __forceinline__ void last_layer_one_wave(const MlpArgs& m, char* act, float* part, int lane) {
-    constexpr int MS = 64, KQ = 4;
+// Output layer of the one- and two-wave workgroups (NW = 1, 2), out_dim <= 32: this wave's NQL non-empty K-quarters one
+// after the other, each its own accumulator chain on a 32-feature tile x 2 sample tiles, all kept in registers until
+// every operand has been read (part aliases the activation image); its empty quarters are written as +0.
+template <int KQ, int NQL, int NQW>
+__device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act, float* part, int q0, int lane) {
+    constexpr int MS = 64;
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc[NQL][1][2];
 #pragma unroll
     for (int q = 0; q < NQL; ++q) {
-        const WSrc wl = make_wsrc(m.wp[m.n_layers - 1] + (size_t)(q * KQ) * 256, lane);
+        const WSrc wl = make_wsrc(m.wp[m.n_layers - 1] + (size_t)((q0 + q) * KQ) * 256, lane);
         f32x4 a0[1], a1[1], a2[1];
         prefetch_a<1>(a0, a1, a2, wl, 64);
-        gemm_tile<1, 2>(acc[q], a0, a1, a2, wl, 1, KQ, act + act_off<MS>(q * KQ, j, h), nullptr);
+        gemm_tile<1, 2>(acc[q], a0, a1, a2, wl, 1, KQ, act + act_off<MS>((q0 + q) * KQ, j, h), nullptr);
     }
-    __syncthreads();   // (one wave: an LDS fence) every operand has been read
+    __syncthreads();   // every operand has been read (one wave: just the LDS fence)
     const int od = m.out_dim;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (d < od) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < NQW; ++q)
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
-                    part[(q * od + d) * MS + 32 * st + j] = (q < NQL) ? acc[q < NQL ? q : 0][0][st][r] : 0.0f;
+                    part[((q0 + q) * od + d) * MS + 32 * st + j] = (q < NQL) ? acc[q < NQL ? q : 0][0][st][r] : 0.0f;
         }
     }
     __syncthreads();
@@ -806,24 +808,27 @@ __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& 
 template <int HID, int NST, bool JVP = false, int NW = 4>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre, char* x0, char* act, int wave,
                                          int lane ST_PARAM) {
-    static_assert(NW == 4 || (NW == 1 && NST == 2 && HID <= 128), "one-wave workgroups: 64-sample passes, width <= 128");
+    static_assert(NW == 4 || (NST == 2 && ((NW == 1 && HID <= 128) || (NW == 2 && HID == 256))),
+                  "one-wave workgroups: width <= 128; two-wave workgroups: width 256; both on 64-sample passes");
     constexpr int NFT = HID / (32 * NW);
     constexpr int FTT = HID / 32;
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
-    // the output layer's K is split into four quarters whose partial sums are added ((p0+p1)+p2)+p3.  NW = 4: a wave
-    // per quarter, HID/32 k-groups each.  NW = 1: the quarters are those of the 128-wide net (4 k-groups each, as in
-    // the zero-padded 128-wide kernel and in the oracle's kernel order), of which HID/32 are not empty.
-    constexpr int KQ = (NW == 4) ? HID / 32 : 4;
-    constexpr int NQL = (NW == 4) ? 1 : HID / 32;
+    // the output layer's K is split into four quarters whose partial sums are added ((p0+p1)+p2)+p3: KQ k-groups each
+    // (at width 64 the quarters of the 128-wide net, as in the zero-padded 128-wide kernel and the oracle's kernel
+    // order), NQW = 4 / NW of them per wave starting at q0, of which NQL are not empty.
+    constexpr int KQ = (HID < 128 ? 128 : HID) / 32;
+    constexpr int NQW = 4 / NW;
+    constexpr int NQL = (NQW * KQ * 8 <= HID) ? NQW : HID / (KQ * 8);
+    const int q0 = wave * NQW;
     const bool small_out = (NST == 2) && m.wsmall != nullptr;
     f32x4 wsm[2 * KQ * NQL];
     constexpr bool SKEWED = mlp_is_skewed<HID, NST, JVP>();
     if constexpr (SKEWED) {
         hidden_skewed<HID, NW>(m, pre, x0, act, wave, lane ST_ARG);
         ST(1)
-        if (small_out) small_load_w<KQ, NQL>(m, wave, lane, wsm);
+        if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
         __syncthreads();
         ST(1)
     } else {
@@ -860,19 +865,19 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
         if (nhid > 1) __syncthreads();
         ST(2)
         store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
-        if (small_out) small_load_w<KQ, NQL>(m, wave, lane, wsm);
+        if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
         ST(3)
         __syncthreads();
         ST(4)
     }
     float* part = (float*)act;
     if (small_out) {
-        last_layer_small<KQ, NQL>(m, wsm, act, part, wave, lane);
+        last_layer_small<KQ, NQL, NQW>(m, wsm, act, part, q0, lane);
         ST(6)
         return;
     }
-    if constexpr (NW == 1) {
-        last_layer_one_wave<NQL>(m, act, part, lane);   // out_dim <= 32 (rt_set_mlp)
+    if constexpr (NW != 4) {
+        last_layer_quarters<KQ, NQL, NQW>(m, act, part, q0, lane);   // out_dim <= 32 (rt_set_mlp)
         ST(6)
         return;
     }

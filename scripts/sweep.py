@@ -25,7 +25,9 @@ CONFIGS = [
     ("width sweep 8/21 g_units=128x10 RT_IS_NARROW=0 (four-wave kernel)", 8, 21, 128, 40000, 0.1, 0.1, 4.0e8),
     ("width sweep 2/2 g_units=64x10 (one-wave workgroups)", 2, 2, 64, 40000, 0.1, 0.5, 8.0e8),
     ("width sweep 2/2 g_units=128x10 (one-wave workgroups)", 2, 2, 128, 40000, 0.1, 0.5, 4.0e8),
-    ("width sweep 8/21 g_units=256x10", 8, 21, 256, 40000, 0.1, 0.1, 2.0e8),
+    ("width sweep 8/21 g_units=256x10 (two-wave workgroups)", 8, 21, 256, 40000, 0.1, 0.1, 2.0e8),
+    ("width sweep 8/21 g_units=256x10 RT_IS_NARROW=0 (four-wave kernel)", 8, 21, 256, 40000, 0.1, 0.1, 2.0e8),
+    ("width sweep 2/2 g_units=256x10 (two-wave workgroups)", 2, 2, 256, 40000, 0.1, 0.5, 2.0e8),
     ("width sweep 8/21 g_units=512x10 (reference width)", 8, 21, 512, 40000, 0.1, 0.1, 1.0e8),
     ("width sweep 8/21 g_units=1024x10 (32-sample passes)", 8, 21, 1024, 40000, 0.1, 0.1, 0.25e8),
 ]
