@@ -373,7 +373,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic[0] if traffic else None, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "is_fused_kernel<512, 2, false, %s>" % ("true" if share else "false"),
+                         "kernel": "is_fused_kernel<512, 2, false, %s, 4>" % ("true" if share else "false"),
                          "kernel_ms_avg": ctr["kernel_ms"] / max(1, ctr["launches"]),
                          "launches": ctr["launches"],
                          "flops_per_sample_eval": ctr["flops"] / max(1, ctr["sample_evals"])},

@@ -203,6 +203,14 @@ int rt_reset_counters(rt_ctx* ctx);
 /* Device facts the host side needs for work partitioning. */
 int rt_device_cu_count(rt_ctx* ctx, int* out);
 
+/* The shares of the fused kernel's passes that the eight workgroup classes blockIdx % 8 — the eight XCDs, to which
+ * workgroups are dispatched round-robin — get in this context's next chip-filling launch (they sum to 1; 1/8 each at
+ * first).  The XCDs of one MI355X do not run at one clock (1-2 % apart, stable from launch to launch), and a persistent
+ * kernel with equal shares ends with its slowest XCD; after every long launch the library re-derives the shares, on the
+ * device, from how long each class took.  Results never depend on them.  RT_IS_BALANCE=0 (read by rt_ctx_create)
+ * keeps equal shares.  No counterpart in the reference.  Waits for the context's stream. */
+int rt_get_xcd_shares(rt_ctx* ctx, double* shares8);
+
 /* CRC-32C (Castagnoli) of n bytes, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint files carry
  * per index block and per tensor, which `tf.train.Saver.restore` / `ckpt.restore` verify (main_density_est.py:402,410;
  * roundtrip.py:57) and roundtrip_amd/checkpoint.py verifies through this.  Host code, needs no context or GPU. */

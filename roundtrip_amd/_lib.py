@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
     "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs", "rt_is_estimate_dev_noalloc",
-    "rt_philox4x32_10", "rt_crc32c",
+    "rt_philox4x32_10", "rt_crc32c", "rt_get_xcd_shares",
     "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
     "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
@@ -81,6 +81,7 @@ def load():
     lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
     lib.rt_is_estimate_dev_noalloc.argtypes = lib.rt_is_estimate_dev.argtypes
     lib.rt_philox4x32_10.argtypes = [vp, vp, i64, vp]
+    lib.rt_get_xcd_shares.argtypes = [vp, C.POINTER(C.c_double)]
     lib.rt_crc32c.restype = C.c_uint32
     lib.rt_crc32c.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
     lib.rt_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -356,6 +357,12 @@ class Engine(object):
 
     def reset_counters(self):
         self._chk(self._lib.rt_reset_counters(self._h))
+
+    def xcd_shares(self):
+        """Shares of the fused kernel's passes the eight XCD classes get in the next chip-filling launch (rt_is.h)."""
+        a = (C.c_double * 8)()
+        self._chk(self._lib.rt_get_xcd_shares(self._h, a))
+        return np.array(list(a))
 
     def cu_count(self):
         n = C.c_int()

@@ -88,6 +88,9 @@ struct rt_ctx {
     double ms_harvested = 0.0;              // durations already folded in by harvest_events()
     uint64_t launches_harvested = 0;
     void* scratch = nullptr;                // this device's copy of the `scratch` array (see above)
+    double* d_bal = nullptr;                // XCD balance: 9 cumulative shares (balance_update_kernel) ...
+    unsigned long long* d_wg_times = nullptr;   // ... and the workgroups' start / end times of the last launch (2 x 1024)
+    bool balance = true;                    // RT_IS_BALANCE=0 (read by rt_ctx_create) turns the balancing off
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
@@ -303,9 +306,16 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
     a.inv_scale = 1.0 / scale;
     a.inv_df = 1.0 / df;
     a.half_dfp1 = 0.5 * (df + 1.0);
+    // (set below, once the grid is known: a.bal, a.wg_times)
 
     const Carve cv = carve_for(G.hid, MS, G.args.k0, dx, dy, 64 * G.nw);
     const int grid = (int)((a.p_total < grid_max) ? a.p_total : grid_max);
+    // XCD balance: only launches that fill the chip (grid a multiple of 8, <= 1024 workgroups) use the shares, and only
+    // long ones (>= 256 passes per workgroup: a pass of granularity is then < 0.4 % of the launch) update them
+    const bool use_bal = ctx->balance && ctx->d_bal && grid == grid_max && grid % 8 == 0 && grid <= 1024;
+    const bool upd_bal = use_bal && a.p_total / grid >= 256;
+    a.bal = use_bal ? ctx->d_bal : nullptr;
+    a.wg_times = upd_bal ? ctx->d_wg_times : nullptr;
     if (pb.timed) {
         if (ctx->events_used == MAX_EVENT_PAIRS) {
             rc = harvest_events(ctx);
@@ -342,6 +352,11 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
         if (pl.rem == 0 && cnt && e_lo + cnt == pl.ppp) per_point -= pl.ppp * MS - S;   // the part-full last main pass
         ctx->flops_acc += (double)N * (double)per_point * G.flops_per_row;
         ctx->evals_acc += (uint64_t)N * (uint64_t)per_point;
+    }
+    if (upd_bal) {
+        hipLaunchKernelGGL(balance_update_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_bal,
+                           (const unsigned long long*)ctx->d_wg_times, grid);
+        HIPCHK(ctx, hipGetLastError());
     }
     if (!out) return RT_OK;
     hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
@@ -484,6 +499,24 @@ int rt_ctx_create(int device, rt_ctx** out) {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
     ctx->lds_allowed.reserve(64);    // so that no launch path grows it (rt_is_estimate_dev_noalloc allocates nothing)
+    {   // XCD balance state (see balance_update_kernel): equal shares to start with
+        if (const char* v = getenv("RT_IS_BALANCE")) ctx->balance = !(v[0] == '0');
+        void* p = nullptr;
+        e = hipMalloc(&p, 16 * sizeof(double) + 2 * 1024 * sizeof(unsigned long long));
+        if (e == hipSuccess) {
+            double init[16] = {0};
+            for (int i = 0; i <= 8; ++i) init[i] = (double)i / 8.0;
+            e = hipMemcpy(p, init, sizeof init, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            if (p) (void)hipFree(p);
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(nullptr, RT_EHIP, std::string("XCD balance state: ") + hipGetErrorString(e));
+        }
+        ctx->d_bal = (double*)p;
+        ctx->d_wg_times = (unsigned long long*)((double*)p + 16);
+    }
     if (device < MAX_DEVICES) {
         // the device address of this GPU's copy of `scratch`, looked up once per device with that device current
         std::lock_guard<std::mutex> lk(g_scratch_mu);
@@ -513,6 +546,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout,
                       &ctx->b_csend, &ctx->b_crecv};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (ctx->d_bal) (void)hipFree(ctx->d_bal);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -903,9 +937,29 @@ int rt_debug_stamps(rt_ctx* ctx, unsigned long long* out48, int reset) {
 }
 #endif
 
+#if defined(RT_STAMPS) && RT_STAMPS == 2
+int rt_debug_wg_ticks(rt_ctx* ctx, unsigned long long* out2048) {
+    if (!ctx || !out2048) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_wg_ticks), sizeof(unsigned long long) * 2048));
+    return RT_OK;
+}
+#endif
+
 int rt_device_cu_count(rt_ctx* ctx, int* out) {
     if (!ctx || !out) return RT_EINVAL;
     *out = ctx->cu_count;
+    return RT_OK;
+}
+
+int rt_get_xcd_shares(rt_ctx* ctx, double* shares8) {
+    if (!ctx || !shares8) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double cum[9];
+    HIPCHK(ctx, hipMemcpy(cum, ctx->d_bal, sizeof cum, hipMemcpyDeviceToHost));
+    for (int x = 0; x < 8; ++x) shares8[x] = cum[x + 1] - cum[x];
     return RT_OK;
 }
 

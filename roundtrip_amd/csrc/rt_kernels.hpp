@@ -40,6 +40,10 @@ struct IsArgs {
     double inv_scale;
     double inv_df;
     double half_dfp1;       // (df+1)/2
+    // XCD balance (see balance_update_kernel): cumulative shares of the eight workgroup classes blockIdx % 8, or nullptr
+    // for equal shares; and where every workgroup leaves its start / end time (nullptr: nowhere)
+    const double* bal;
+    unsigned long long* wg_times;
 };
 
 struct Carve {
@@ -143,11 +147,26 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
     for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
     st.t = __builtin_amdgcn_s_memtime();
 #endif
+    if (a.wg_times && tid == 0) a.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     // this workgroup's share of the main passes and of the leftover passes (a leftover pass costs a few percent more
-    // than a main one — per-slot query points — so they are dealt evenly too, not left to the last workgroups)
+    // than a main one — per-slot query points — so they are dealt evenly too, not left to the last workgroups).
+    // Workgroups are dispatched to the eight XCDs round-robin, and the XCDs of one chip do not run at one clock (1-2 %
+    // apart, stable from launch to launch): class x = blockIdx % 8 gets the share [bal[x], bal[x+1]) of the passes, which
+    // balance_update_kernel sets from how long each class took in the launch before; inside a class, equal shares.
     const int64_t n_left = a.p_total - a.p_main;
-    const int64_t m_lo = a.p_main * (int64_t)blockIdx.x / gridDim.x, m_hi = a.p_main * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    const int64_t l_lo = n_left * (int64_t)blockIdx.x / gridDim.x, l_hi = n_left * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    int64_t m_lo, m_hi, l_lo, l_hi;
+    if (a.bal) {
+        const int x = blockIdx.x & 7, per = gridDim.x >> 3;
+        const int64_t i = blockIdx.x >> 3;
+        const double f0 = a.bal[x], f1 = a.bal[x + 1];              // bal[0] = 0 and bal[8] = 1 exactly
+        const int64_t M0 = (int64_t)((double)a.p_main * f0), M1 = (int64_t)((double)a.p_main * f1);
+        const int64_t L0 = (int64_t)((double)n_left * f0), L1 = (int64_t)((double)n_left * f1);
+        m_lo = M0 + (M1 - M0) * i / per; m_hi = M0 + (M1 - M0) * (i + 1) / per;
+        l_lo = L0 + (L1 - L0) * i / per; l_hi = L0 + (L1 - L0) * (i + 1) / per;
+    } else {
+        m_lo = a.p_main * (int64_t)blockIdx.x / gridDim.x; m_hi = a.p_main * ((int64_t)blockIdx.x + 1) / gridDim.x;
+        l_lo = n_left * (int64_t)blockIdx.x / gridDim.x; l_hi = n_left * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    }
     const int64_t n_mine = (m_hi - m_lo) + (l_hi - l_lo);
     // (query point, pass of that point — an absolute entry index in [j_lo, j_lo + ppp)) of the current main pass,
     // advanced incrementally.  (Narrowing this loop state to
@@ -274,13 +293,50 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
         }
         if (!left && ++j_u == a.j_lo + a.ppp) { j_u = a.j_lo; ++n_u; }
     }
+    if (a.wg_times && tid == 0) a.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #ifdef RT_STAMPS
 #if RT_STAMPS == 2
     st.acc[0] = __builtin_amdgcn_s_memtime() - st.t;
 #endif
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[wave * NSTAMP + i], st.acc[i]);
+#if RT_STAMPS == 2
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_wg_ticks[2 * blockIdx.x] = st.acc[0];
+        g_wg_ticks[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, common to all CUs: end time
+    }
 #endif
+#endif
+}
+
+// XCD balance, closed on the device: after a (long enough) launch of the fused kernel one wave turns the workgroups'
+// start / end times (s_memrealtime: 100 MHz, common to the chip) into the shares of the NEXT launch.  Class x did the
+// share w_x = bal[x+1] - bal[x] of the passes in T_x = its last workgroup's end - the first workgroup's start, so it runs
+// at a rate proportional to w_x / T_x, and shares proportional to those rates make the classes finish together.  Shares
+// are clamped to [0.8, 1.25] / 8; the cumulative table keeps bal[0] = 0 and bal[8] = 1 exactly.  Stream order makes the
+// table safe to read in the next launch's prologue.  The work a query point gets does not depend on any of this: only
+// WHICH workgroup runs a pass changes, and every pass writes its own pair.
+__global__ __launch_bounds__(64) void balance_update_kernel(double* bal, const unsigned long long* wg_times, int grid) {
+    const int lane = threadIdx.x;
+    unsigned long long t0 = ~0ull;
+    for (int b = lane; b < grid; b += 64) { const unsigned long long v = wg_times[2 * b]; t0 = v < t0 ? v : t0; }
+    for (int o = 32; o; o >>= 1) { const unsigned long long v = __shfl_xor(t0, o); t0 = v < t0 ? v : t0; }
+    unsigned long long te = 0;                                   // lanes x, x+8, ...: the latest end of class x
+    for (int b = lane; b < grid; b += 64) { const unsigned long long v = wg_times[2 * b + 1]; te = v > te ? v : te; }
+    for (int o = 32; o >= 8; o >>= 1) { const unsigned long long v = __shfl_xor(te, o); te = v > te ? v : te; }
+    const double T = (double)(te - t0);                          // lane x < 8: T_x (grid % 8 == 0, so class = lane % 8)
+    const double w = (lane < 8) ? bal[lane + 1] - bal[lane] : 0.0;
+    double r = (lane < 8 && T > 0.0) ? w / T : 0.0;
+    double sum = r;
+    for (int o = 4; o; o >>= 1) sum += __shfl_xor(sum, o);      // over lanes 0..7 (lanes >= 8 carry 0 and are ignored)
+    double nw = (sum > 0.0) ? r / sum : 0.125;
+    nw = fmin(fmax(nw, 0.8 / 8.0), 1.25 / 8.0);
+    double tot = nw;
+    for (int o = 4; o; o >>= 1) tot += __shfl_xor(tot, o);
+    nw /= tot;
+    double cum = nw;                                             // inclusive prefix over lanes 0..7
+    for (int o = 1; o < 8; o <<= 1) { const double v = __shfl_up(cum, o); if ((lane & 7) >= o) cum += v; }
+    if (lane < 7) bal[lane + 1] = cum;                           // bal[0] and bal[8] stay 0 and 1
 }
 
 // out[k*out_stride + n] for sd index k: merges the E pairs of query point n (n < N, this launch's block) in a fixed

@@ -33,6 +33,7 @@ struct MlpArgs {
 #ifdef RT_STAMPS
 constexpr int NSTAMP = 14;
 __device__ unsigned long long g_stamps[4 * NSTAMP];
+__device__ unsigned long long g_wg_ticks[2 * 1024];   // per workgroup: ticks from kernel start to its end, and its start stamp
 struct Stamps { unsigned long long t, acc[NSTAMP]; };
 #define ST_PARAM , Stamps& st
 #define ST_ARG , st

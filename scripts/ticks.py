@@ -2,6 +2,7 @@
 slowest wave) from a -DRT_STAMPS=2 build, per 64-sample pass, against the cycles of pure MFMA time at the unpadded
 algorithmic flops (1 180 672 at dx = dy = 2, G = 10 x 512).  RT_IS_LIB=build_diag/<lib>.so python scripts/ticks.py [dx dy]"""
 import ctypes as C, os, sys
+os.environ["RT_IS_BALANCE"] = "0"      # equal shares: workgroup 0 runs exactly 800 passes (read by rt_ctx_create)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from roundtrip_amd import _lib, Generator

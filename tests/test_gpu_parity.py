@@ -726,3 +726,37 @@ def test_gamma_path_draws_match_the_restatement(engine, make_nets, df):
     assert close.mean() > 0.999, (df, close.mean())
     u = (xs[0].astype(np.float64) - xhat[0]) / 0.5
     assert stats.kstest(u[:, 3], stats.t(df).cdf).pvalue > 1e-3
+
+
+def test_xcd_balance_changes_no_result(engine, make_nets, monkeypatch):
+    """The XCDs of one chip run at slightly different clocks; after every long launch the library re-derives, on the
+    device, the share of the passes each of the eight workgroup classes (blockIdx % 8) gets next.  Only WHICH workgroup
+    runs a pass changes: a context with the balancing off (RT_IS_BALANCE=0) gives the same bits, launch after launch,
+    and the shares stay a partition of unity within their clamps."""
+    gw, gb, hw, hb = make_nets(2, 2)
+    rng = np.random.RandomState(77)
+    N, S = 4096, 6400 * 3            # 1200 passes per workgroup: long enough to update the shares
+    y = rng.standard_normal((N, 2)) * 0.5
+    monkeypatch.setenv("RT_IS_BALANCE", "0")
+    plain = _lib.Engine(0)
+    monkeypatch.delenv("RT_IS_BALANCE")
+    try:
+        plain.set_mlp(G, gw, gb)
+        plain.set_mlp(H, hw, hb)
+        engine.set_mlp(G, gw, gb)
+        engine.set_mlp(H, hw, hb)
+        xhat = engine.mlp_forward(H, y.astype(np.float32))
+        want = plain.is_estimate(y, xhat, S, 0.1, 0.5)
+        assert np.allclose(plain.xcd_shares(), 0.125, rtol=0, atol=0)          # off: equal shares, never updated
+        for _ in range(3):
+            got = engine.is_estimate(y, xhat, S, 0.1, 0.5)
+            assert np.array_equal(got, want)
+            sh = engine.xcd_shares()
+            assert abs(sh.sum() - 1.0) < 1e-12 and sh.min() >= 0.8 / 8 - 1e-12 and sh.max() <= 1.25 / 8 + 1e-12
+        # a short launch uses the shares without touching them, and packed leftover passes are dealt by them too
+        before = engine.xcd_shares()
+        a = engine.is_estimate(y[:300], xhat[:300], 1000 + 16, 0.1, 0.5, log=False)
+        assert np.array_equal(a, plain.is_estimate(y[:300], xhat[:300], 1000 + 16, 0.1, 0.5, log=False))
+        assert np.array_equal(engine.xcd_shares(), before)
+    finally:
+        plain.close()
