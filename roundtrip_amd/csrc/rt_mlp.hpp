@@ -817,7 +817,7 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
     // the output layer's K is split into four quarters whose partial sums are added ((p0+p1)+p2)+p3: KQ k-groups each
-    // (at width 64 the quarters of the 128-wide net, as in the zero-padded 128-wide kernel and the oracle's kernel
+    // (at width 64 the quarters of the 128-wide net, as in the zero-padded 128-wide kernel and the CPU checker's kernel
     // order), NQW = 4 / NW of them per wave starting at q0, of which NQL are not empty.
     constexpr int KQ = (HID < 128 ? 128 : HID) / 32;
     constexpr int NQW = 4 / NW;
