@@ -53,6 +53,10 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 constexpr int MAX_DEVICES = 64;
 void* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on HIP device i (nullptr: not looked up yet)
 std::mutex g_scratch_mu;
+// XCD shares (balance_update_kernel) a destroyed context of this process left for HIP device i: the relative speeds of a
+// chip's XCDs are a property of the chip, so the next context on it starts from them instead of from equal shares
+double g_bal_seed[MAX_DEVICES][9];
+bool g_bal_seeded[MAX_DEVICES];
 
 // ----------------------------------------------------------------------------------------------
 // Host side
@@ -506,6 +510,10 @@ int rt_ctx_create(int device, rt_ctx** out) {
         if (e == hipSuccess) {
             double init[16] = {0};
             for (int i = 0; i <= 8; ++i) init[i] = (double)i / 8.0;
+            if (ctx->balance && device < MAX_DEVICES) {
+                std::lock_guard<std::mutex> lk(g_scratch_mu);
+                if (g_bal_seeded[device]) memcpy(init, g_bal_seed[device], sizeof g_bal_seed[device]);
+            }
             e = hipMemcpy(p, init, sizeof init, hipMemcpyHostToDevice);
         }
         if (e != hipSuccess) {
@@ -546,7 +554,16 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout,
                       &ctx->b_csend, &ctx->b_crecv};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
-    if (ctx->d_bal) (void)hipFree(ctx->d_bal);
+    if (ctx->d_bal) {
+        double cum[9];
+        if (ctx->balance && ctx->device < MAX_DEVICES &&
+            hipMemcpy(cum, ctx->d_bal, sizeof cum, hipMemcpyDeviceToHost) == hipSuccess && cum[0] == 0.0 && cum[8] == 1.0) {
+            std::lock_guard<std::mutex> lk(g_scratch_mu);
+            memcpy(g_bal_seed[ctx->device], cum, sizeof cum);
+            g_bal_seeded[ctx->device] = true;
+        }
+        (void)hipFree(ctx->d_bal);
+    }
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
