@@ -197,6 +197,15 @@ def test_v2_evaluate_grid_caller(tmp_path):
     assert np.array_equal(np.load("%s/2d_grid_IS_density_pre_at_7.npy" % m.save_dir), want)
     assert np.array_equal(res["px_CF"], m.estimate_px_with_CF(grid, sd_x=0.4, log=False).reshape(n, n))
     assert np.all(np.isfinite(res["px_CF"])) and np.all(res["px_IS"] >= 0)
+    # the samplers of roundtrip_amd.datasets return (X, Y) from load_all(), like util.py's: the data is the first item
+    from roundtrip_amd import datasets
+    params2 = dict(params, dataset="indep_gmm", sd_x=0.05)
+    m2 = Roundtrip(params2, timestamp="ev2", random_seed=5)
+    m2.data_sampler = datasets.GMM_indep_sampler(N=200, sd=0.1, dim=2, n_components=3, bound=1)
+    res2 = m2.evaluate(1, n=6)
+    X = m2.data_sampler.load_all()[0]
+    assert res2["data_z"].shape == X.shape and np.array_equal(res2["data_z"], m2.e_net(X))
+    assert res2["px_IS"].shape == (6, 6) and res2["v1"].min() == -1.5
 
 
 def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path, monkeypatch):
