@@ -72,8 +72,10 @@ const char* rt_last_error(const rt_ctx* ctx);
  *   W[l]      dims[l] x dims[l+1] floats, row-major;  b[l]: dims[l+1] floats
  *   lrelu_alpha  leaky-ReLU slope applied after every layer but the last (0.2 in the reference,
  *             model.py:5-6); must be in [0, 1].
- * Limits: hidden widths <= 1024 (any mix: they are zero-padded, exactly, to 128/256/512/1024), dims[0] <= 128,
+ * Limits: hidden widths <= 1024 (any mix: they are zero-padded, exactly, to 64/128/256/512/1024), dims[0] <= 128,
  * dims[n_layers] <= 128, and the activation image must fit the 160 KiB LDS; otherwise RT_EUNSUPPORTED.
+ * Nets of width <= 256 with dims[n_layers] <= 32 run as one- or two-wave workgroups (four / two to a CU)
+ * with bit-identical results; RT_IS_NARROW=0 in the environment (read here) keeps them on the four-wave kernels.
  */
 int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims,
                const float* const* W, const float* const* b, float lrelu_alpha);
