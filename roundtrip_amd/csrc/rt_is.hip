@@ -532,6 +532,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             void* ptr = nullptr;
             e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
             if (e != hipSuccess || !ptr) {
+                (void)hipFree(ctx->d_bal);
                 (void)hipStreamDestroy(ctx->stream);
                 delete ctx;
                 return fail(nullptr, RT_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
