@@ -134,10 +134,12 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
 
     // zero the padded rows of the x0 image once: rows >= dx are never written again
     for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // many-dimensional sets (the SHARE kernels: YearPredictionMSD 20/90, ...): the scorer reads the output layer's bias
+    // many-dimensional sets (the SHARE kernels: YearPredictionMSD 20/90, ...) and one- / two-wave workgroups, whose threads
+    // score more dims each: the scorer reads the output layer's bias
     // once per output dim and thread; from LDS that is a broadcast read next to the partial sums, from global memory a
     // round trip per dim
-    if (SHARE) for (int d = tid; d < dy; d += NTHREADS) ob[d] = m.bp[m.n_layers - 1][d];
+    constexpr bool OB = SHARE || NW != 4;     // (the four-wave one-call kernel — the 2-D sets, the bench — keeps its code)
+    if (OB) for (int d = tid; d < dy; d += NTHREADS) ob[d] = m.bp[m.n_layers - 1][d];
     // orders the zero-fill against the first pass's put_x0 writes to the same words: a workgroup whose first pass is a
     // leftover pass (p_main == 0, a pair range of only the last entry, p_main < grid) meets no other barrier before them
     __syncthreads();
@@ -231,8 +233,24 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
         const int64_t n_c = valid ? sl.n : 0;           // in-bounds row for the loads of slots that carry nothing
         double se = 0.0, lw = 0.0;
         auto score = [&](const auto* yrow, const auto* centre) __attribute__((always_inline)) {
-            for (int d = p; d < dy; d += NP) {
-                const float g_d = SHARE ? mlp_out_nobias<MS>(m, part, d, s) + ob[d] : mlp_out<MS>(m, part, d, s);
+            int d0 = p;
+            if constexpr (OB) {
+                // many output dims per thread: four at a time, every LDS read of the four issued before the first use
+                // (one read-latency per four dims instead of per dim); same terms added in the same order
+                for (; d0 + 3 * NP < dy; d0 += 4 * NP) {
+                    float g[4];
+                    double yv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        g[i] = mlp_out_nobias<MS>(m, part, d0 + i * NP, s) + ob[d0 + i * NP];
+                        yv[i] = (double)yrow[d0 + i * NP];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const double diff = yv[i] - (double)g[i]; se += diff * diff; }
+                }
+            }
+            for (int d = d0; d < dy; d += NP) {
+                const float g_d = OB ? mlp_out_nobias<MS>(m, part, d, s) + ob[d] : mlp_out<MS>(m, part, d, s);
                 const double diff = (double)yrow[d] - (double)g_d;
                 se += diff * diff;
             }
