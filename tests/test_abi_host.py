@@ -665,6 +665,21 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
         assert p.returncode == 0 and "rank ok" in o, o + e
 
 
+def test_rccl_is_loaded_on_first_use_and_fails_loudly_without_a_gpu():
+    """rt_comm_* dlopen librccl.so.1 on first use and resolve their entry points from that handle: on a machine
+    without a GPU that much works, and RCCL's own refusal comes back as RT_ECOMM with its text — never a silent
+    fallback.  (With a GPU the same call is exercised by the -m gpu one-rank communicator test.)"""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present: covered by test_rccl_branch_world_size_1")
+    script = ("import ctypes as C, sys; sys.path.insert(0, %r); from roundtrip_amd import _lib; lib = _lib.load(); "
+              "b = C.create_string_buffer(_lib.RT_COMM_ID_BYTES); rc = lib.rt_comm_unique_id(b); "
+              "print('RC', rc, lib.rt_last_error(None).decode()); print('NULL', lib.rt_comm_unique_id(None))" % ROOT)
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "RC %d " % _lib.RT_ECOMM in res.stdout and "GetUniqueId" in res.stdout, res.stdout
+    assert "cannot load RCCL" not in res.stdout and "NULL 1" in res.stdout
+
+
 def test_bench_parent_starts_ranks_before_touching_the_gpu():
     """bench.py --gpus N without a launcher: the parent spawns N rank processes with the launcher's environment and
     relays the first failure's exit code.  Without a GPU the ranks fail at rt_ctx_create — loudly, not silently."""
