@@ -58,7 +58,7 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     const int part_bytes = 4 * out_dim * ms * 4;
     if (part_bytes > act_bytes) act_bytes = part_bytes;
     c.act = off; off += act_bytes;
-    c.scr = off; off += 2 * nthreads * 8;            // per (phase, sample): squared error, log weight
+    c.scr = off; off += 2 * (nthreads < NTHREADS ? NTHREADS : nthreads) * 8;   // per (phase, sample): squared error, log weight
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
     c.ob = off; off += ((out_dim * 4 + 15) / 16) * 16;   // the output layer's bias, for the scorer (SHARE kernels)
@@ -231,30 +231,35 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
         const Slot sl = slot_of(s2);
         const bool valid = sl.valid;
         const int64_t n_c = valid ? sl.n : 0;           // in-bounds row for the loads of slots that carry nothing
-        double se = 0.0, lw = 0.0;
-        auto score = [&](const auto* yrow, const auto* centre) __attribute__((always_inline)) {
-            int d0 = p;
+        // The sums over dims are defined on NPH = 256 / MS PHASES: phase ph adds its dims ph, ph + NPH, ... in ascending
+        // order, and the phases' sums are added in phase order (phase D).  In the four-wave kernel a thread is a phase
+        // (NP = NPH); a thread of the one- / two-wave kernels carries NPH / NP phases, each in its own accumulator — the
+        // same additions in the same order, so the same bits whatever the workgroup shape.
+        constexpr int NPH = 256 / MS, PPT = NPH / NP;
+        static_assert(PPT >= 1 && PPT * NP == NPH, "phases per thread");
+        auto score = [&](const auto* yrow, const auto* centre, const int ph, double& se, double& lw) __attribute__((always_inline)) {
+            int d0 = ph;
             if constexpr (OB) {
                 // many output dims per thread: four at a time, every LDS read of the four issued before the first use
                 // (one read-latency per four dims instead of per dim); same terms added in the same order
-                for (; d0 + 3 * NP < dy; d0 += 4 * NP) {
+                for (; d0 + 3 * NPH < dy; d0 += 4 * NPH) {
                     float g[4];
                     double yv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        g[i] = mlp_out_nobias<MS>(m, part, d0 + i * NP, s) + ob[d0 + i * NP];
-                        yv[i] = (double)yrow[d0 + i * NP];
+                        g[i] = mlp_out_nobias<MS>(m, part, d0 + i * NPH, s) + ob[d0 + i * NPH];
+                        yv[i] = (double)yrow[d0 + i * NPH];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { const double diff = yv[i] - (double)g[i]; se += diff * diff; }
                 }
             }
-            for (int d = d0; d < dy; d += NP) {
+            for (int d = d0; d < dy; d += NPH) {
                 const float g_d = OB ? mlp_out_nobias<MS>(m, part, d, s) + ob[d] : mlp_out<MS>(m, part, d, s);
                 const double diff = (double)yrow[d] - (double)g_d;
                 se += diff * diff;
             }
-            for (int d = p; d < dx; d += NP) {
+            for (int d = ph; d < dx; d += NPH) {
                 double x;
                 if (GIVEN) x = valid ? a.xs[((size_t)n_c * a.S + sl.si) * dx + d] : 0.0;
                 else x = (double)*(const float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
@@ -262,18 +267,23 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
                 lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
             }
         };
-        if (!left) score((const double*)yb, (const float*)xh);
-        else score(a.y + n_c * dy, a.xhat + n_c * dx);
-        scr[p * MS + s] = se;
-        scr[NTHREADS + p * MS + s] = lw;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int ph = p + q * NP;
+            double se = 0.0, lw = 0.0;
+            if (!left) score((const double*)yb, (const float*)xh, ph, se, lw);
+            else score(a.y + n_c * dy, a.xhat + n_c * dx, ph, se, lw);
+            scr[ph * MS + s] = se;
+            scr[NPH * MS + ph * MS + s] = lw;
+        }
         __syncthreads();
         // ---- D. this pass's log-sum-exp pairs (wave 0; lane = sample slot) ----------------------
         if (wave == 0) {
             double se_t = 0.0, lw_t = 0.0;
             if (lane < MS) {
-                se_t = scr[lane]; lw_t = scr[NTHREADS + lane];
+                se_t = scr[lane]; lw_t = scr[NPH * MS + lane];
 #pragma unroll
-                for (int qq = 1; qq < NP; ++qq) { se_t += scr[qq * MS + lane]; lw_t += scr[NTHREADS + qq * MS + lane]; }
+                for (int qq = 1; qq < NPH; ++qq) { se_t += scr[qq * MS + lane]; lw_t += scr[NPH * MS + qq * MS + lane]; }
             }
             const bool live = lane < MS && valid;
             for (int k = 0; k < a.n_sd; ++k) {

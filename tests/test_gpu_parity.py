@@ -27,6 +27,13 @@ G, H = _lib.RT_MLP_G, _lib.RT_MLP_H
 DIMS = [(2, 2), (3, 6), (5, 9), (8, 17), (8, 21), (20, 90)]
 
 
+def glorot_nets(dx, hid, dy, seed, n_hidden=4):
+    """A biased Glorot generator [dx, hid x n_hidden, dy]."""
+    rng = np.random.RandomState(seed)
+    ws, bs = is_ref.glorot_mlp([dx] + [hid] * n_hidden + [dy], rng)
+    return ws, [rng.uniform(-0.1, 0.1, size=b.shape).astype(np.float32) for b in bs]
+
+
 def reference_samples(xhat, scale, df, S, seed=0):
     """Draws as the reference does (main_density_est.py:316-318) with numpy's legacy global RNG."""
     np.random.seed(seed)
@@ -760,3 +767,59 @@ def test_xcd_balance_changes_no_result(engine, make_nets, monkeypatch):
         assert np.array_equal(engine.xcd_shares(), before)
     finally:
         plain.close()
+
+
+@pytest.mark.parametrize("hid", [64, 100, 128, 256])
+@pytest.mark.parametrize("dx,dy", [(2, 2), (8, 21), (5, 32)])
+def test_one_and_two_wave_workgroups_equal_the_four_wave_kernel(engine, make_nets, monkeypatch, hid, dx, dy):
+    """Hidden widths <= 128 (256) with an output dim <= 32 run as one-wave (two-wave) workgroups, four (two) to a CU.
+    Every entry point must give the SAME BITS as the four-wave kernel (a context created under RT_IS_NARROW=0, which
+    zero-pads width 64 / 100 to 128) — forward, Jacobian, the estimate on Philox draws with packed leftover passes,
+    on given samples, for several sd values, as pair ranges — and agree with the oracle in kernel order."""
+    gw, gb = glorot_nets(dx, hid, dy, 7)
+    monkeypatch.setenv("RT_IS_NARROW", "0")
+    wide = _lib.Engine(0)
+    try:
+        wide.set_mlp(G, gw, gb)
+        monkeypatch.delenv("RT_IS_NARROW")
+        engine.set_mlp(G, gw, gb)
+        og = c_oracle.OracleMlp(gw, gb)
+        rng = np.random.RandomState(hid + dx)
+        x = (rng.standard_normal((150, dx)) * 2).astype(np.float32)
+        f = engine.mlp_forward(G, x)
+        assert np.array_equal(f, wide.mlp_forward(G, x))
+        assert np.array_equal(f, og.forward(x, order=c_oracle.ORDER_KERNEL))
+        o1, j1 = engine.mlp_jacobian(G, x[:70])
+        o2, j2 = wide.mlp_jacobian(G, x[:70])
+        assert np.array_equal(o1, o2) and np.array_equal(j1, j2)
+        N = 4 * engine.cu_count() + 37                      # more passes than workgroups of either kind
+        y = rng.standard_normal((N, dy)) * 0.3
+        xhat = (rng.standard_normal((N, dx)) * 0.3).astype(np.float32)
+        for S, log in ((64 * 3 + 16, True), (40, False), (200, True)):
+            kw = dict(df=1.0, seed=9, y_index_base=5)
+            got = engine.is_estimate(y, xhat, S, 0.3, 0.2, log=log, **kw)
+            assert np.array_equal(got, wide.is_estimate(y, xhat, S, 0.3, 0.2, log=log, **kw)), (S, log)
+        S = 64 * 3 + 16
+        got = engine.is_estimate(y, xhat, S, 0.3, 0.2, **kw)
+        xs = engine.draw_samples(xhat[:40], S, 0.2, seed=9, y_index_base=5).astype(np.float64)
+        assert np.array_equal(xs, wide.draw_samples(xhat[:40], S, 0.2, seed=9, y_index_base=5).astype(np.float64))
+        want = c_oracle.is_estimate_given_samples(og, y[:40], xhat[:40], xs, 0.3, 0.2, 1.0, True, c_oracle.ORDER_KERNEL, 8)
+        np.testing.assert_allclose(got[:40], want, rtol=1e-12, atol=1e-13)
+        gs = engine.is_estimate_given_samples(y[:40], xhat[:40], xs, 0.3, 0.2)
+        assert np.array_equal(gs, wide.is_estimate_given_samples(y[:40], xhat[:40], xs, 0.3, 0.2))
+        np.testing.assert_allclose(gs, want, rtol=1e-12, atol=1e-13)
+        multi = engine.is_estimate_multi(y, xhat, S, [0.3, 0.1, 0.7], 0.2, seed=9, y_index_base=5)
+        assert np.array_equal(multi, wide.is_estimate_multi(y, xhat, S, [0.3, 0.1, 0.7], 0.2, seed=9, y_index_base=5))
+        assert np.array_equal(multi[0], got)
+        E = engine.is_pair_count(S)
+        assert E == wide.is_pair_count(S) == 4
+        parts = [engine.is_pairs(y[:50], xhat[:50], S, [0.3], 0.2, lo, hi, seed=9, y_index_base=5)
+                 for lo, hi in ((0, 1), (1, 3), (3, 4))]
+        whole = wide.is_pairs(y[:50], xhat[:50], S, [0.3], 0.2, 0, E, seed=9, y_index_base=5)
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+        assert np.array_equal(engine.is_merge_pairs(whole, S)[0], got[:50])
+        # a many-dimensional non-integer-df draw goes through the one-thread-per-sample sampler here
+        a = engine.is_estimate(y[:64], xhat[:64], 300, 0.3, 0.2, df=2.5, seed=3)
+        assert np.array_equal(a, wide.is_estimate(y[:64], xhat[:64], 300, 0.3, 0.2, df=2.5, seed=3))
+    finally:
+        wide.close()
