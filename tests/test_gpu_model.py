@@ -394,10 +394,12 @@ def test_bench_launches_its_own_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["query_points_total"] == 512 and d["result_check"]["finite"]
     assert d["value"] > 0 and d["roofline"]["launches"] == 1
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-                          "--grid", "16", "--sample-size", "640", "--no-live-traffic", "--cpu-points", "8",
+    res = subprocess.run([sys.executable, "-X", "importtime", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1",
+                          "--warmup", "0", "--grid", "16", "--sample-size", "640", "--no-live-traffic", "--cpu-points", "8",
                           "--cpu-points-numpy", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    imported = [l.split("|")[-1].strip() for l in res.stderr.splitlines() if l.startswith("import time:")]
+    assert "numpy" in imported and "roundtrip_amd" in imported and not [m for m in imported if m.split(".")[0] == "torch"]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
     assert "matches GPU on this sample: True" in d["cpu_baseline"]["sample"]
