@@ -111,7 +111,9 @@ int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);
  *   v_i = -dy*log(sqrt(2pi)*sd_y) - |y - G(x_i)|^2 / (2 sd_y^2) - dx*log(sqrt(2pi)) - |x_i|^2/2
  *         - sum_d t.logpdf(xhat_d - x_id, df, 0, scale)
  * Reduction (:339-345): log( sum_i exp(v_i) ) - log(S).
- * Samples whose score is not finite carry weight 0.
+ * Non-finite scores behave as in the reference (:340-345): a score of -inf (G overflowed to inf) weighs 0; a NaN or +inf
+ * score makes the point's estimate NaN; if every score is -inf the estimate is NaN under log_flag = 1 ((-inf) - (-inf))
+ * and 0 under log_flag = 0.
  * A call of more than 2^28 sample-evals (N*S; the environment variable RT_IS_MAX_LAUNCH_EVALS, read by rt_ctx_create,
  * overrides the bound) runs as several kernel launches over blocks of query points; the result is the same.
  */
