@@ -404,3 +404,119 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
     assert "matches GPU on this sample: True" in d["cpu_baseline"]["sample"]
     assert "matches GPU on this sample: True" in d["cpu_baseline"]["numpy_restatement"]["sample"]
+
+
+_COMM_DOUBLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "comm_double", "librccl_double.so")
+
+
+def test_two_ranks_through_rt_comm(tmp_path):
+    """N = 2 through the SAME code the multi-GPU node runs — dist.init's rendezvous, rt_comm_init, the gathers sized
+    per * world, the max-reduce, the barrier — on two ranks that share the one GPU of the test box.  RCCL refuses that, so
+    RT_RCCL_LIB points rt_is.hip's loader at tests/comm_double (the six nccl* entry points over shared memory): this
+    checks THIS repo's side of the collective (counts, offsets, block order, y_index_base) bit for bit against the
+    one-process answers, not RCCL.  No torch in the rank processes."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    assert os.path.exists(_COMM_DOUBLE), "build() compiles tests/comm_double"
+    import socket, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys\nsys.path.insert(0, %r)\n" % root + textwrap.dedent("""
+        import numpy as np
+        from roundtrip_amd import Generator, RoundtripModel, dist as rdist
+        rank = int(os.environ["RANK"])
+        rng = np.random.RandomState(21)
+        g = Generator(3, 6, "g_net", nb_layers=10, nb_units=512, rng=rng)
+        h = Generator(6, 3, "h_net", nb_layers=10, nb_units=256, rng=rng)
+        m = RoundtripModel(g, h, data="arem", df=1, device=0)        # both ranks on the one GPU of the test box
+        y = np.random.RandomState(22).standard_normal((13, 6)) * 0.1
+        def run():
+            return dict(IS=m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False),
+                        multi=m._estimate_is_multi(y, [0.05, 0.1], 0.1, 900, 1, True),
+                        CF=m.estimate_py_with_CF(y, 0, sd_y=0.1, save=False))
+        one = run()                                                  # before init: one process, all 13 points
+        alone = {S: m.estimate_py_with_IS(y[:1], 0, sd_y=0.1, scale=0.1, sample_size=S, save=False) for S in (900, 650)}
+        assert m.init_distributed() == (rank, 2) and rdist.world() == (rank, 2) and m.engine.comm_info() == (rank, 2)
+        eng = m.engine
+        # the raw collectives: rows arrive in rank order
+        v = np.arange(5, dtype=np.float64) + 10.0 * rank
+        assert np.array_equal(eng.comm_all_gather(v), np.stack([np.arange(5.0), np.arange(5.0) + 10.0]))
+        assert np.array_equal(eng.comm_all_reduce_max([float(rank), -float(rank)]), [1.0, 0.0])
+        src, dst = eng.to_device(v), eng.dev_alloc(2 * v.nbytes)
+        eng.comm_all_gather_dev(src, v.size, dst)
+        eng.sync()
+        assert np.array_equal(eng.from_device(dst, (2, 5), np.float64), np.stack([np.arange(5.0), np.arange(5.0) + 10.0]))
+        eng.dev_free(src); eng.dev_free(dst)
+        eng.comm_barrier()
+        # ragged blocks: 13 points = 7 + 6, 3 points = 2 + 1, 1 point = 1 + 0
+        for n in (13, 3, 1):
+            lo, hi = rdist.shard_bounds(n, 2, rank)
+            assert np.array_equal(rdist.all_gather_blocks(np.arange(lo, hi, dtype=np.float64), n), np.arange(n))
+        whole = np.random.RandomState(1).standard_normal((3, 5, 2, 2))
+        lo, hi = rdist.shard_bounds(5, 2, rank)
+        assert np.array_equal(rdist.all_gather_ranges(whole[:, lo:hi], 5, axis=1), whole)
+        # the drop-in class: sharded query points, every rank gets the full result, the one-process bits
+        got = run()
+        for k in got:
+            assert got[k].shape == one[k].shape and np.array_equal(got[k], one[k]), (k, got[k], one[k])
+        for S in (900, 650):                                         # fewer points than ranks: samples split
+            assert np.array_equal(m.estimate_py_with_IS(y[:1], 0, sd_y=0.1, scale=0.1, sample_size=S, save=False), alone[S])
+        m.split_samples = True
+        assert np.array_equal(m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False), one["IS"])
+        rdist.shutdown()
+        assert "torch" not in sys.modules
+        print("rank %d ok" % rank)
+    """))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RT_COMM_RUN_ID="t-%d" % os.getpid(), RT_RCCL_LIB=_COMM_DOUBLE, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=280))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in so, "rank %d: %s %s" % (r, so[-2000:], se[-3000:])
+
+
+def test_bench_two_ranks_default_backend(tmp_path):
+    """`python bench.py --gpus 2` on its default backend (rt_comm_*: device-pointer gather on the engine's stream, barrier
+    and max-over-ranks through the C ABI), the two ranks sharing the box's one GPU and the communicator coming from
+    tests/comm_double (see above).  One JSON line, n_gpus = 2, every result finite; and the gathered result is the
+    two-block answer: its mean equals the mean of a one-GPU run over the same 2 x 256 points."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2",
+                          "--warmup", "1", "--grid", "16", "--sample-size", "640"],
+                         env=dict(env, RT_RCCL_LIB=_COMM_DOUBLE), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["query_points_total"] == 512 and d["result_check"]["finite"]
+    assert d["config"]["collective"] == "rccl all-gather" and d["steps"] == 2 and d["value"] > 0
+    # the same 512 global points (the 16 x 16 tile twice, global indices 0..511) evaluated by one process
+    import numpy as np
+    sys.path.insert(0, root)
+    import bench as B
+    from roundtrip_amd import _lib
+    dx, dy, sd, scale, _, log = B.WORKLOADS["grid"][:6]
+    g, h = B.build_nets(dx, dy)
+    eng = _lib.Engine(0)
+    eng.set_mlp(_lib.RT_MLP_G, g.weights, g.biases, g.alpha)
+    eng.set_mlp(_lib.RT_MLP_H, h.weights, h.biases, h.alpha)
+    y = np.tile(B.grid_points(16), (2, 1))
+    xhat = eng.mlp_forward(_lib.RT_MLP_H, y.astype(np.float32))
+    want = eng.is_estimate(y, xhat, 640, sd, scale, df=1.0, seed=0, log=log)
+    eng.close()
+    assert d["result_check"]["mean"] == float(want.mean())
