@@ -505,6 +505,19 @@ def test_bench_two_ranks_default_backend(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["query_points_total"] == 512 and d["result_check"]["finite"]
     assert d["config"]["collective"] == "rccl all-gather" and d["steps"] == 2 and d["value"] > 0
+    # the driver's launch line for N > 1 (one rank per process under torch.distributed.run): the same line again
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--grid", "16", "--sample-size", "640"],
+                         env=dict(env, RT_RCCL_LIB=_COMM_DOUBLE, OMP_NUM_THREADS="1"), capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["result_check"] == d["result_check"] and d2["config"] == d["config"]
     # the same 512 global points (the 16 x 16 tile twice, global indices 0..511) evaluated by one process
     import numpy as np
     sys.path.insert(0, root)
