@@ -242,6 +242,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
+    if args.gpus > 1:
+        # this pool's host driver only supports dmabuf IPC: without it RCCL's peer mappings fail (hipIpcGetMemHandle).
+        # Read when the HSA runtime starts, i.e. before the first HIP call of this process and of the ranks it starts.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))          # nothing above has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
