@@ -823,3 +823,44 @@ def test_one_and_two_wave_workgroups_equal_the_four_wave_kernel(engine, make_net
         assert np.array_equal(a, wide.is_estimate(y[:64], xhat[:64], 300, 0.3, 0.2, df=2.5, seed=3))
     finally:
         wide.close()
+
+
+def test_two_contexts_on_two_threads(make_nets):
+    """rt_is.h: 'a context is not re-entrant; different contexts may be used from different threads'.  Two contexts on
+    HIP device 0, each driven by its own thread at the same time (ctypes releases the GIL, so the calls do overlap on the
+    GPU), with different generators: every result equals what the same context returns when it runs alone."""
+    import threading
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    cases = []
+    for dx, dy, S in ((2, 2, 5000), (8, 21, 3000)):
+        gw, gb, hw, hb = make_nets(dx, dy)
+        eng = _lib.Engine(0)
+        eng.set_mlp(G, gw, gb)
+        eng.set_mlp(H, hw, hb)
+        y = np.random.RandomState(dx).standard_normal((300, dy))
+        xhat = eng.mlp_forward(H, y.astype(np.float32))
+        alone = (eng.is_estimate(y, xhat, S, 0.1, 0.5), eng.mlp_jacobian(G, xhat)[1],
+                 eng.is_estimate_multi(y, xhat, S, [0.05, 0.2], 0.5))
+        cases.append((eng, y, xhat, S, alone))
+    got, errs = {}, []
+
+    def work(k):
+        eng, y, xhat, S, _ = cases[k]
+        try:
+            for _ in range(3):
+                got[k] = (eng.is_estimate(y, xhat, S, 0.1, 0.5), eng.mlp_jacobian(G, xhat)[1],
+                          eng.is_estimate_multi(y, xhat, S, [0.05, 0.2], 0.5))
+        except Exception as e:          # surfaced below: an exception in a thread does not fail a test by itself
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(240)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in threads)
+    for k, (eng, _, _, _, alone) in enumerate(cases):
+        for a, b in zip(alone, got[k]):
+            assert np.array_equal(a, b)
+        eng.close()
