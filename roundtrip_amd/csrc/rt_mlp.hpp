@@ -194,9 +194,6 @@ __device__ __forceinline__ void prefetch_a(f32x4 (&a0)[NFT], f32x4 (&a1)[NFT], f
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
-// MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
-// a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
 // Last k-group of a hidden layer (ACT0: 64-sample passes, not the Jacobian kernel).  Sample tile 0's MFMAs go first;
 // its leaky-ReLU (6 VALU instructions per MFMA) then issues in the shadow of sample tile 1's MFMAs, so half of the
 // epilogue's arithmetic costs no time.  Every accumulator still sees its k's in the same order.  The sched_barriers
@@ -223,6 +220,9 @@ __device__ __forceinline__ void final_stage_act0(f32x16 (&acc)[NFT][NST], const 
         }
 }
 
+// nkg must be a positive multiple of 4.  Operands of k-group kg+3 are requested while k-group kg's
+// MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
+// a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
 // ACT0: on return sample tile 0's accumulators already hold lrelu(pre-activation) (see final_stage_act0).
 template <int NFT, int NST, bool JVP = false, bool ACT0 = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
@@ -361,7 +361,7 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
 // Every accumulator sees its k's in the same order as in the plain schedule, so results are bit-identical.
 // Ring slots: weights of k-group g in w[g % 6]; A's operand of k-group g in bA[g % 6]; B's in bB[(g + 2) % 6];
 // all three are requested three stages before their first use.  The stages are unrolled at compile time (skew_steady),
-// so a slot is a fixed register and any NKG >= 8 works: widths 128, 256 and 512.
+// so a slot is a fixed register and any NKG >= 8 works: widths 64 (one-wave workgroups), 128, 256 and 512.
 // ----------------------------------------------------------------------------------------------
 // LDS operand reads of the skewed schedule: byte offset `off` from this lane's base bl.  ds_read_b128 carries a 16-bit
 // immediate offset; with a second base at +64 KB every (compile-time) offset is an immediate and the fully unrolled
