@@ -796,10 +796,10 @@ __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act,
 
 // Runs the MLP on the MS samples whose (padded) inputs sit in the x0 image.  On return
 // part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
-// (bias not yet added).  Must be called by all 256 threads.
+// (bias not yet added).  Must be called by all 64 * NW threads of the workgroup.
 // pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
 template <int HID, int NST, bool JVP = false>
-constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 128, 256, 512
+constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 64, 128, 256, 512
 
 template <int HID, int NST, bool JVP = false, int NW = 4>
 __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
