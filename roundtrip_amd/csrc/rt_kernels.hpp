@@ -11,7 +11,8 @@
 //                    samples of q = MS / rem consecutive query points share one pass — slot s carries sample
 //                    ppp*MS + s % rem of point g*q + s / rem — instead of one 3/4-empty pass per point.
 // Workgroup b runs main passes [p_main*b/G, p_main*(b+1)/G) and then leftover passes [L*b/G, L*(b+1)/G): every workgroup
-// gets the same number of passes of either kind (+-1).
+// gets the same number of passes of either kind (+-1) — or, in a launch that fills the chip, the share of its XCD class
+// (IsArgs::bal, balance_update_kernel), split evenly inside the class.
 // Every pass reduces ITS samples of ONE query point to (max v, sum exp(v - max)) and stores the pair:
 //   partial[((n*E + e)*n_sd + k)*2 ..+1],  e = j for a main pass, e = ppp for the point's share of a leftover pass.
 // is_finalize_kernel merges a point's E pairs in a fixed order, so the result does not depend on how passes were dealt to
@@ -61,7 +62,7 @@ __host__ __device__ inline Carve carve_for(int hid, int ms, int k0, int in_dim, 
     c.scr = off; off += 2 * (nthreads < NTHREADS ? NTHREADS : nthreads) * 8;   // per (phase, sample): squared error, log weight
     c.yb = off; off += ((out_dim * 8 + 15) / 16) * 16;
     c.xh = off; off += ((in_dim * 4 + 15) / 16) * 16;
-    c.ob = off; off += ((out_dim * 4 + 15) / 16) * 16;   // the output layer's bias, for the scorer (SHARE kernels)
+    c.ob = off; off += ((out_dim * 4 + 15) / 16) * 16;   // the output layer's bias, for the scorer (SHARE and NW != 4 kernels)
     c.total = off;
     return c;
 }
@@ -109,7 +110,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // SHARE: the NP threads of a sample slot share the sample's Philox calls (chosen by the host when a sample takes more
 // than one call, dx + df > 4); otherwise one thread draws the whole sample.  Same values either way (see draw_sample); a
 // separate instantiation because the register allocation of the one-call kernel — the 2-D sets, the bench — is kept as is.
-// NW = 1 (rt_mlp.hpp): the workgroup is one wave; grid = 4 per CU.
+// NW = 1 / 2 (rt_mlp.hpp): the workgroup is one wave / two waves; grid = 4 / 2 per CU.
 template <int HID, int NST, bool GIVEN, bool SHARE = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
     constexpr int NTHREADS = 64 * NW;     // (shadows the namespace-scope default of 256)
