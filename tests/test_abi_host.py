@@ -738,3 +738,24 @@ def test_reference_draws_mode_host_logic(tmp_path, monkeypatch):
     tail = m._reference_draws_block(y, 0.4, 0.2, S, 3, True)(y[3:], 3)
     assert np.array_equal(np.concatenate(StubEngine.seen), xs_ref[3:])
     np.testing.assert_allclose(tail, want[3:], rtol=1e-12)
+
+
+def test_every_entry_point_has_its_row_in_integration_md():
+    """INTEGRATION.md's table is the maintainer's map from the reference to the C ABI: every function include/rt_is.h
+    declares is named there (grouped spellings such as `rt_x[_dev]` and `rt_ctx_create/destroy` count)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "rt_is.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 36
+    missing = []
+    for n in names:
+        spellings = [n]
+        if n.endswith("_dev"):
+            spellings.append(n[:-4] + "[_dev]")
+        if n == "rt_ctx_destroy":
+            spellings.append("rt_ctx_create/destroy")
+        if not any(s in doc for s in spellings):
+            missing.append(n)
+    assert not missing, missing
