@@ -211,8 +211,10 @@ int rt_device_cu_count(rt_ctx* ctx, int* out);
  * workgroups are dispatched round-robin — get in this context's next chip-filling launch (they sum to 1; 1/8 each at
  * first).  The XCDs of one MI355X do not run at one clock (1-2 % apart, stable from launch to launch), and a persistent
  * kernel with equal shares ends with its slowest XCD; after every long launch the library re-derives the shares, on the
- * device, from how long each class took.  Results never depend on them.  RT_IS_BALANCE=0 (read by rt_ctx_create)
- * keeps equal shares.  No counterpart in the reference.  Waits for the context's stream. */
+ * device, from how long each class took; the first long call of a process on a GPU runs a short first block of its
+ * query points (one more launch) to measure them for the rest of the call.  Results never depend on them.
+ * RT_IS_BALANCE=0 (read by rt_ctx_create) keeps equal shares.  No counterpart in the reference.  Waits for the context's
+ * stream. */
 int rt_get_xcd_shares(rt_ctx* ctx, double* shares8);
 
 /* CRC-32C (Castagnoli) of n bytes, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint files carry

@@ -95,6 +95,7 @@ struct rt_ctx {
     double* d_bal = nullptr;                // XCD balance: 9 cumulative shares (balance_update_kernel) ...
     unsigned long long* d_wg_times = nullptr;   // ... and the workgroups' start / end times of the last launch (2 x 1024)
     bool balance = true;                    // RT_IS_BALANCE=0 (read by rt_ctx_create) turns the balancing off
+    uint64_t bal_updates = 0;               // share updates enqueued so far (a context seeded from an earlier one starts at 1)
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
@@ -361,6 +362,7 @@ int is_enqueue_block(rt_ctx* ctx, const PairBuf& pb, const double* y, const floa
         hipLaunchKernelGGL(balance_update_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_bal,
                            (const unsigned long long*)ctx->d_wg_times, grid);
         HIPCHK(ctx, hipGetLastError());
+        ctx->bal_updates++;
     }
     if (!out) return RT_OK;
     hipLaunchKernelGGL(is_finalize_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
@@ -420,7 +422,24 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     }
     // (blocks of one call reuse the buffer from its start: they run in stream order)
     const PairBuf pb = fixed ? *fixed : PairBuf{(double*)ctx->b_partial.p, ctx->b_partial.cap, true};
-    for (int64_t n0 = 0; n0 < N; n0 += per) {
+    int64_t n_first = 0;
+    if (ctx->balance && ctx->bal_updates == 0 && !xs) {
+        // The XCD shares are still the equal ones (first long call of the process on this GPU): a call that is at least
+        // four times a share update's minimum runs that minimum — 320 passes per workgroup, about 0.15 s — as a block of
+        // its own first, so that the rest of the call already runs on measured shares (0.7 % of its time) instead of
+        // only the next call.  Blocks are independent: no result changes.
+        const IsPlan p1 = is_plan(1, S, G.nst);
+        const int64_t grid_max = (int64_t)ctx->cu_count * (4 / G.nw);
+        const int64_t n_cal = (320 * grid_max + p1.ppp - 1) / (p1.ppp > 0 ? p1.ppp : 1);
+        const bool can_balance = ctx->d_bal && grid_max % 8 == 0 && grid_max <= 1024;   // is_enqueue_block's conditions
+        if (can_balance && p1.ppp > 0 && n_cal <= per && 4 * n_cal <= N) {
+            const int rc = is_enqueue_block(ctx, pb, y, xhat, nullptr, n_cal, y_index_base, S, n_sd, sd_ys, scale, df, seed,
+                                            log_flag, out, N);
+            if (rc) return rc;
+            n_first = n_cal;
+        }
+    }
+    for (int64_t n0 = n_first; n0 < N; n0 += per) {
         const int64_t nb = (N - n0 < per) ? N - n0 : per;
         const int rc = is_enqueue_block(ctx, pb, y + n0 * dy, xhat + n0 * dx, xs ? xs + (size_t)n0 * S * dx : nullptr, nb,
                                         y_index_base + n0, S, n_sd, sd_ys, scale, df, seed, log_flag, out + n0, N);
@@ -512,7 +531,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             for (int i = 0; i <= 8; ++i) init[i] = (double)i / 8.0;
             if (ctx->balance && device < MAX_DEVICES) {
                 std::lock_guard<std::mutex> lk(g_scratch_mu);
-                if (g_bal_seeded[device]) memcpy(init, g_bal_seed[device], sizeof g_bal_seed[device]);
+                if (g_bal_seeded[device]) { memcpy(init, g_bal_seed[device], sizeof g_bal_seed[device]); ctx->bal_updates = 1; }
             }
             e = hipMemcpy(p, init, sizeof init, hipMemcpyHostToDevice);
         }

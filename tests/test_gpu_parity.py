@@ -864,3 +864,49 @@ def test_two_contexts_on_two_threads(make_nets):
         for a, b in zip(alone, got[k]):
             assert np.array_equal(a, b)
         eng.close()
+
+
+def test_first_long_call_of_a_process_measures_the_shares_on_a_first_block(tmp_path):
+    """A process's first long call on a GPU has no measured XCD shares yet: it runs the minimum that updates them
+    (320 passes per workgroup) as a block of its own, and the rest of the call on the measured shares — two launches, the
+    next call one; the bits are those of a context with the balancing off.  (Fresh process: contexts of one process hand
+    their shares on.)"""
+    import subprocess, sys, textwrap
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n" % (root, os.path.join(root, "tests"))
+                      + textwrap.dedent("""
+        import numpy as np
+        from roundtrip_amd import _lib
+        from conftest import glorot
+        gw, gb = glorot([2] + [512] * 10 + [2], 1234, 5)
+        N, S = 2048, 19200                                   # 300 passes per point; 320 x 256 passes = 274 points first
+        y = np.random.RandomState(3).standard_normal((N, 2)) * 0.5
+        xhat = (y * 0.3).astype(np.float32)
+        eng = _lib.Engine(0)
+        eng.set_mlp(0, gw, gb)
+        assert np.array_equal(eng.xcd_shares(), np.full(8, 0.125))
+        eng.reset_counters()
+        first = eng.is_estimate(y, xhat, S, 0.1, 0.5)
+        c1 = eng.counters()
+        sh = eng.xcd_shares()
+        second = eng.is_estimate(y, xhat, S, 0.1, 0.5)
+        c2 = eng.counters()
+        assert c1["launches"] == 2 and c2["launches"] == 3, (c1, c2)
+        assert c1["sample_evals"] == N * S and c2["sample_evals"] == 2 * N * S
+        assert abs(sh.sum() - 1.0) < 1e-12 and not np.array_equal(sh, np.full(8, 0.125))
+        short = eng.is_estimate(y[:500], xhat[:500], S, 0.1, 0.5)      # shares known: one launch
+        assert eng.counters()["launches"] == 4
+        os.environ["RT_IS_BALANCE"] = "0"
+        plain = _lib.Engine(0)
+        plain.set_mlp(0, gw, gb)
+        want = plain.is_estimate(y, xhat, S, 0.1, 0.5)
+        assert plain.counters()["launches"] == 1
+        assert np.array_equal(first, want) and np.array_equal(second, want) and np.array_equal(short, want[:500])
+        print("calibration ok")
+    """))
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, cwd=str(tmp_path),
+                         env={k: v for k, v in os.environ.items() if k != "RT_IS_BALANCE"})
+    assert res.returncode == 0 and "calibration ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
