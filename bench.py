@@ -255,6 +255,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
+    # one step = ONE launch of the fused kernel (the library would otherwise split a process's first long call into a
+    # short share-measuring block and the rest, DESIGN.md §4 "XCD balance"): the launches rocprofv3 --stats averages for
+    # this command are then all alike, and the timed steps run on measured shares after the first warm-up step either way
+    os.environ.setdefault("RT_IS_FIRST_BLOCK", "0")
     from roundtrip_amd import _lib, dist as rdist
     dev_index = 0 if args.share_gpu else local_rank
     use_gloo = args.backend == "gloo"
@@ -338,11 +342,11 @@ def main():
     if rank == 0:
         threading.Thread(target=heartbeat, daemon=True).start()
 
-    # not a warm-up step: one tiny launch of each kernel so that code-object loading (library load, by the metric's
-    # definition outside the measured call) never lands in a timed step, even under --warmup 0
+    # not a warm-up step: one tiny H forward, so that loading the library's code object (all kernels are in one; by the
+    # metric's definition library load is outside the measured call) never lands in a timed step, even under --warmup 0.
+    # No extra launch of the fused kernel: the rocprofv3 --stats average of this command is over equal launches.
     if n_mine > 0:
         eng.mlp_forward_dev(_lib.RT_MLP_H, y32_dev, min(n_mine, 64), xhat_dev)
-        eng.is_estimate_dev(y_dev, xhat_dev, min(n_mine, 64), 64, sd, scale, out_dev, df=1.0, seed=0, log=log, y_index_base=lo)
         eng.sync()
     for _ in range(args.warmup):
         step()

@@ -96,6 +96,7 @@ struct rt_ctx {
     unsigned long long* d_wg_times = nullptr;   // ... and the workgroups' start / end times of the last launch (2 x 1024)
     bool balance = true;                    // RT_IS_BALANCE=0 (read by rt_ctx_create) turns the balancing off
     uint64_t bal_updates = 0;               // share updates enqueued so far (a context seeded from an earlier one starts at 1)
+    bool first_block = true;                // RT_IS_FIRST_BLOCK=0 (read by rt_ctx_create): no measuring first block (is_enqueue)
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
@@ -423,11 +424,12 @@ int is_enqueue(rt_ctx* ctx, const double* y, const float* xhat, const double* xs
     // (blocks of one call reuse the buffer from its start: they run in stream order)
     const PairBuf pb = fixed ? *fixed : PairBuf{(double*)ctx->b_partial.p, ctx->b_partial.cap, true};
     int64_t n_first = 0;
-    if (ctx->balance && ctx->bal_updates == 0 && !xs) {
+    if (ctx->balance && ctx->first_block && ctx->bal_updates == 0 && !xs) {
         // The XCD shares are still the equal ones (first long call of the process on this GPU): a call that is at least
         // four times a share update's minimum runs that minimum — 320 passes per workgroup, about 0.15 s — as a block of
         // its own first, so that the rest of the call already runs on measured shares (0.7 % of its time) instead of
-        // only the next call.  Blocks are independent: no result changes.
+        // only the next call.  Blocks are independent: no result changes.  (RT_IS_FIRST_BLOCK=0 keeps such a call in one
+        // launch: bench.py sets it so that every step stays ONE launch of the kernel its rocprofv3 summary averages.)
         const IsPlan p1 = is_plan(1, S, G.nst);
         const int64_t grid_max = (int64_t)ctx->cu_count * (4 / G.nw);
         const int64_t n_cal = (320 * grid_max + p1.ppp - 1) / (p1.ppp > 0 ? p1.ppp : 1);
@@ -524,6 +526,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     ctx->lds_allowed.reserve(64);    // so that no launch path grows it (rt_is_estimate_dev_noalloc allocates nothing)
     {   // XCD balance state (see balance_update_kernel): equal shares to start with
         if (const char* v = getenv("RT_IS_BALANCE")) ctx->balance = !(v[0] == '0');
+        if (const char* v = getenv("RT_IS_FIRST_BLOCK")) ctx->first_block = !(v[0] == '0');
         void* p = nullptr;
         e = hipMalloc(&p, 16 * sizeof(double) + 2 * 1024 * sizeof(unsigned long long));
         if (e == hipSuccess) {

@@ -905,8 +905,16 @@ def test_first_long_call_of_a_process_measures_the_shares_on_a_first_block(tmp_p
         want = plain.is_estimate(y, xhat, S, 0.1, 0.5)
         assert plain.counters()["launches"] == 1
         assert np.array_equal(first, want) and np.array_equal(second, want) and np.array_equal(short, want[:500])
+        # RT_IS_FIRST_BLOCK=0 (bench.py sets it: one launch per step): the first long call stays one launch and the shares
+        # are measured for the next call only
+        del os.environ["RT_IS_BALANCE"]
+        os.environ["RT_IS_FIRST_BLOCK"] = "0"
+        whole = _lib.Engine(0)                               # (eng is still alive: nothing has been handed on yet)
+        whole.set_mlp(0, gw, gb)
+        assert np.array_equal(whole.is_estimate(y, xhat, S, 0.1, 0.5), want) and whole.counters()["launches"] == 1
+        assert not np.array_equal(whole.xcd_shares(), np.full(8, 0.125))
         print("calibration ok")
     """))
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, cwd=str(tmp_path),
-                         env={k: v for k, v in os.environ.items() if k != "RT_IS_BALANCE"})
+                         env={k: v for k, v in os.environ.items() if k not in ("RT_IS_BALANCE", "RT_IS_FIRST_BLOCK")})
     assert res.returncode == 0 and "calibration ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
