@@ -73,7 +73,10 @@ const char* rt_last_error(const rt_ctx* ctx);
  *   lrelu_alpha  leaky-ReLU slope applied after every layer but the last (0.2 in the reference,
  *             model.py:5-6); must be in [0, 1].
  * Limits: hidden widths <= 1024 (any mix: they are zero-padded, exactly, to 64/128/256/512/1024), dims[0] <= 128,
- * dims[n_layers] <= 128, and the activation image must fit the 160 KiB LDS; otherwise RT_EUNSUPPORTED.
+ * dims[n_layers] <= 128, and a pass must fit the 160 KiB of LDS: 256 B per input dim (rounded up to 8 dims) + the
+ * larger of 256 B per unit of the padded hidden width (128 at width 1024) and 1 KiB per output dim (512 B at width 1024)
+ * + about 6 KiB — e.g. at width 512 at most 104 input dims, at output dim 128 at most 104 input dims at any width;
+ * otherwise RT_EUNSUPPORTED, with the numbers in the message.
  * Nets of width <= 256 with dims[n_layers] <= 32 run as one- or two-wave workgroups (four / two to a CU)
  * with bit-identical results; RT_IS_NARROW=0 in the environment (read here) keeps them on the four-wave kernels.
  */

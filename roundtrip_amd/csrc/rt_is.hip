@@ -627,8 +627,16 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
             hid = h1;
         }
     }
-    if (carve_for(hid, 32 * nst, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64 * nw).total > LDS_MAX)
-        return fail(ctx, RT_EUNSUPPORTED, "input dim too large for this hidden width (LDS budget of 160 KiB)");
+    {
+        const int need = carve_for(hid, 32 * nst, ((dims[0] + 7) / 8) * 8, dims[0], dims[n_layers], 64 * nw).total;
+        if (need > LDS_MAX) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "input dim %d with output dim %d at hidden width %d needs %d bytes of LDS per pass (input "
+                     "image + the larger of the activation image and the output layer's partial sums); the CU has %d",
+                     dims[0], dims[n_layers], hid, need, LDS_MAX);
+            return fail(ctx, RT_EUNSUPPORTED, msg);
+        }
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HostMlp& M = ctx->mlp[which];

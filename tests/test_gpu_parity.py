@@ -918,3 +918,53 @@ def test_first_long_call_of_a_process_measures_the_shares_on_a_first_block(tmp_p
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280, cwd=str(tmp_path),
                          env={k: v for k, v in os.environ.items() if k not in ("RT_IS_BALANCE", "RT_IS_FIRST_BLOCK")})
     assert res.returncode == 0 and "calibration ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("dims", [
+    [104, 512, 512, 128],      # width 512: the x0 image of 104 input dims fills the 160 KB of LDS to within 96 bytes
+    [128, 256, 256, 64],       # the ABI's largest input dim (MAX_IN = 128) at width 256, with an output dim whose four
+                               # partial-sum planes are as large as the activation image
+    [104, 256, 256, 128],      # the largest output dim (MAX_OUT = 128: 128 KB of partial sums) leaves room for 104 input dims
+    [128, 128, 128, 32],       # ... as one-wave workgroups (output dim <= 32)
+    [128, 64, 64, 1],          # ... at width 64
+    [1, 1024, 1024, 128],      # 32-sample passes, one input dim, the largest output dim
+])
+def test_largest_dims_the_kernels_take(engine, dims):
+    """The edges of the supported shapes: forward and Jacobian bit-exact, the estimate on the GPU's own draws equal to
+    the oracle's scoring of them — packed leftover passes included (S = 200 = 3 x 64 + 8)."""
+    rng = np.random.RandomState(sum(dims))
+    gw, gb = is_ref.glorot_mlp(dims, rng)
+    gb = [(rng.standard_normal(b.shape) * 0.05).astype(np.float32) for b in gb]
+    engine.set_mlp(G, gw, gb)
+    og = c_oracle.OracleMlp(gw, gb, 0.2)
+    x = (rng.standard_normal((70, dims[0])) * 0.5).astype(np.float32)
+    assert np.array_equal(engine.mlp_forward(G, x), og.forward(x, order=c_oracle.ORDER_KERNEL))
+    if max(dims[1:-1]) <= 512:
+        out, J = engine.mlp_jacobian(G, x[:33])
+        wout, wJ = og.jacobian(x[:33], c_oracle.ORDER_KERNEL)
+        assert np.array_equal(out, wout) and np.array_equal(J, wJ)
+    N, S = 5, 200
+    y = rng.standard_normal((N, dims[-1])) * 0.3
+    xhat = (rng.standard_normal((N, dims[0])) * 0.3).astype(np.float32)
+    for df in (1.0, 2.5):
+        got = engine.is_estimate(y, xhat, S, 0.5, 0.1, df=df, seed=9)
+        xs = engine.draw_samples(xhat, S, 0.1, df=df, seed=9).astype(np.float64)
+        want = c_oracle.is_estimate_given_samples(og, y, xhat, xs, 0.5, 0.1, df, True, c_oracle.ORDER_KERNEL)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(engine.is_estimate_given_samples(y, xhat, xs, 0.5, 0.1, df), want, rtol=1e-12, atol=1e-13)
+
+
+def test_shapes_beyond_the_lds_budget_are_refused(engine):
+    """One input dim more than fits (k0 = 112 at width 512: 164 KB of LDS), dims above 128 and widths above 1024 are
+    refused by rt_set_mlp with RT_EUNSUPPORTED — nothing is launched; the context keeps working."""
+    z = lambda *s: np.zeros(s, np.float32)
+    fresh = _lib.Engine(0)
+    try:
+        for dims in ([105, 512, 128], [128, 256, 128], [129, 128, 2], [2, 128, 129], [2, 1025, 2]):
+            with pytest.raises(_lib.RtError) as e:
+                fresh.set_mlp(G, [z(a, b) for a, b in zip(dims[:-1], dims[1:])], [z(b) for b in dims[1:]])
+            assert e.value.code == 4, (dims, str(e.value))
+        fresh.set_mlp(G, [z(2, 128), z(128, 2)], [z(128), z(2)])
+        assert np.array_equal(fresh.mlp_forward(G, z(3, 2)), z(3, 2))
+    finally:
+        fresh.close()
