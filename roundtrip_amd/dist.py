@@ -21,6 +21,7 @@ import time
 import numpy as np
 
 _MAGIC = b"RTID"
+_MAGIC_ERR = b"RTER"     # rank 0 could not make the id: 128 bytes of its error text follow instead
 _PORT_SPAN = 16          # candidate rendezvous ports: MASTER_PORT + 1 .. MASTER_PORT + _PORT_SPAN
 _native = None           # (engine, rank, world_size) once init() has run
 _epoch = 0               # rendezvous count of this process: keeps a second init() from meeting a stale first one
@@ -75,12 +76,21 @@ def exchange_id(make_id, rank, world_size, addr, port, timeout=300.0, epoch=0):
                 s.close()
         if srv is None:
             raise RuntimeError("rendezvous: no free port in %d..%d on %s" % (cands[0], cands[-1], addr))
-        uid = make_id()
+        failure = None
+        try:
+            uid = make_id()
+            frame = _MAGIC + uid
+        except Exception as e:          # the peers hear about it (and fail at once) instead of waiting out their timeout
+            failure = e
+            frame = _MAGIC_ERR + ("%s: %s" % (type(e).__name__, e)).encode("utf-8", "replace")[:128].ljust(128, b" ")
+            deadline = min(deadline, time.time() + 15.0)
         served = set()
         try:
             while len(served) < world_size - 1:
                 left = deadline - time.time()
                 if left <= 0:
+                    if failure is not None:
+                        break
                     raise TimeoutError("rendezvous: %d of %d peers arrived within %.0f s"
                                        % (len(served), world_size - 1, timeout))
                 srv.settimeout(min(left, 5.0))
@@ -95,15 +105,17 @@ def exchange_id(make_id, rank, world_size, addr, port, timeout=300.0, epoch=0):
                         peer = struct.unpack("<i", hello[16:])[0]
                         if hello[:16] != tok or not 0 < peer < world_size:
                             continue                                    # not one of ours
-                        conn.sendall(_MAGIC + uid)
+                        conn.sendall(frame)
                         _recv_exact(conn, 1)                            # the peer has it
                         served.add(peer)
                     except (OSError, ConnectionError):
                         continue
         finally:
             srv.close()
+        if failure is not None:
+            raise failure
         return uid
-    last = None
+    last = failed = None
     while time.time() < deadline:
         for p in cands:
             try:
@@ -111,13 +123,18 @@ def exchange_id(make_id, rank, world_size, addr, port, timeout=300.0, epoch=0):
                     conn.settimeout(10.0)
                     conn.sendall(tok + struct.pack("<i", rank))
                     head = _recv_exact(conn, 4)
-                    if head != _MAGIC:
+                    if head not in (_MAGIC, _MAGIC_ERR):
                         continue
                     uid = _recv_exact(conn, 128)
                     conn.sendall(b"k")
+                    if head == _MAGIC_ERR:
+                        failed = uid.decode("utf-8", "replace").rstrip()
+                        break
                     return uid
             except (OSError, ConnectionError) as e:
                 last = e
+        if failed is not None:
+            raise RuntimeError("rendezvous: rank 0 could not make the communicator id (%s)" % failed)
         time.sleep(0.2)
     raise TimeoutError("rendezvous: rank 0 did not answer on %s:%d..%d within %.0f s (%r)"
                        % (addr, cands[0], cands[-1], timeout, last))

@@ -665,6 +665,43 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
         assert p.returncode == 0 and "rank ok" in o, o + e
 
 
+def test_rendezvous_tells_the_peers_when_rank0_cannot_make_the_id(tmp_path):
+    """If rank 0's make_id raises (RCCL missing, say), every peer gets the error text and fails within seconds instead of
+    waiting out its timeout, and rank 0 re-raises its own exception."""
+    import time
+    port = _free_port()
+    script = tmp_path / "r.py"
+    script.write_text(textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        from roundtrip_amd import dist as rdist
+        rank, ws, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        def make_id():
+            raise OSError("cannot load RCCL (test)")
+        t0 = time.time()
+        try:
+            rdist.exchange_id(make_id, rank, ws, "127.0.0.1", port, timeout=120.0)
+            print("no error")
+        except OSError as e:
+            print("rank0 error:", e, "after %%.0f s" %% (time.time() - t0))
+        except RuntimeError as e:
+            print("peer error:", e, "after %%.0f s" %% (time.time() - t0))
+    """ % (ROOT,)))
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(3)]
+    try:
+        outs = [p.communicate(timeout=100) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert time.time() - t0 < 60
+    assert "rank0 error: cannot load RCCL (test)" in outs[0][0], outs[0]
+    for o, e in outs[1:]:
+        assert "peer error:" in o and "OSError: cannot load RCCL (test)" in o, o + e
+
+
 def test_rccl_is_loaded_on_first_use_and_fails_loudly_without_a_gpu():
     """rt_comm_* dlopen librccl.so.1 on first use and resolve their entry points from that handle: on a machine
     without a GPU that much works, and RCCL's own refusal comes back as RT_ECOMM with its text — never a silent
