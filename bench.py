@@ -200,20 +200,34 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_COMM_RUN_ID="bench-%d" % os.getpid())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    import signal
+
+    def stop_ranks(signum, frame):          # the parent is being stopped (a harness's time limit): so are its ranks
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop_ranks)
     rc = 0
     live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 128 - code
-                for o in sorted(live):
-                    procs[o].terminate()
-        if live:
-            time.sleep(0.05)
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    for o in sorted(live):
+                        procs[o].terminate()
+            if live:
+                time.sleep(0.05)
+    finally:
+        for p in procs:                     # nothing of ours is left behind, whatever ended the loop
+            if p.poll() is None:
+                p.terminate()
     return rc
 
 
