@@ -796,3 +796,16 @@ def test_every_entry_point_has_its_row_in_integration_md():
         if not any(s in doc for s in spellings):
             missing.append(n)
     assert not missing, missing
+
+
+def test_python_blocks_of_the_docs_compile():
+    """The binding stubs of INTEGRATION.md and the usage block of README.md are at least syntactically Python."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 0
+    for doc in ("INTEGRATION.md", "README.md"):
+        text = open(os.path.join(root, doc)).read()
+        for i, block in enumerate(re.findall(r"```python\n(.*?)```", text, re.S)):
+            compile(block, "%s block %d" % (doc, i), "exec")
+            n += 1
+    assert n >= 4
