@@ -303,41 +303,6 @@ class Roundtrip(_IsModelBase):
             np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
         return py_est
 
-    def evaluate(self, batch_idx, n=100):
-        """The periodic evaluation of train() (roundtrip.py:208-226): encodes the data set, and for the two 2-D
-        simulation sets evaluates the IS and the Laplace density on the n x n grid (log=False).  The reference
-        turns the two grids into PNGs with plot_2d_grid_data (plotting is out of scope here); the arrays are saved
-        as .npy under the same stems and returned.  `self.data_sampler` (any object with load_all()) must be set,
-        as train() does upstream."""
-        data = self.data_sampler.load_all()
-        if isinstance(data, tuple):       # this repo's samplers return (X, Y) like util.py's; the reference passes X
-            data = data[0]
-        data_z_ = self.e_net(data)
-        np.save('{}/data_z_at_{}.npy'.format(self.save_dir, batch_idx), data_z_)
-        ranges = {'indep_gmm': (-1.5, 1.5, -1.5, 1.5), 'involute': (-6, 5, -5, 5)}
-        out = {'data_z': data_z_}
-        if self.params['dataset'] in ranges:
-            x1_min, x1_max, x2_min, x2_max = ranges[self.params['dataset']]
-            # create_2d_grid_data, src/pyroundtrip/util.py:624-629
-            v1, v2 = np.meshgrid(np.linspace(x1_min, x1_max, n), np.linspace(x2_min, x2_max, n))
-            data_grid = np.vstack((v1.ravel(), v2.ravel())).T
-            px_is = self.estimate_px_with_IS(data_grid, sd_x=self.params['sd_x'], scale=self.params['scale'],
-                                             sample_size=self.params['sample_size'], log=False).reshape((n, n))
-            np.save('{}/2d_grid_IS_density_pre_at_{}.npy'.format(self.save_dir, batch_idx), px_is)
-            px_cf = self.estimate_px_with_CF(data_grid, sd_x=self.params['sd_x'], log=False).reshape((n, n))
-            np.save('{}/2d_grid_CF_density_pre_at_{}.npy'.format(self.save_dir, batch_idx), px_cf)
-            out.update(v1=v1, v2=v2, px_IS=px_is, px_CF=px_cf)
-        return out
-
-    def save(self, fname, data):
-        # roundtrip.py:371-378
-        if fname[-3:] == 'npy':
-            np.save(fname, data)
-        elif fname[-3:] in ('txt', 'csv'):
-            np.savetxt(fname, data, fmt='%.6f')
-        else:
-            raise ValueError('Wrong saving format, please specify either .npy, .txt, or .csv')
-
 
 class RoundtripModel(_IsModelBase):
     """v1 API (main_density_est.py:29-44).  g_net / h_net are roundtrip_amd.nets.Generator objects

@@ -66,7 +66,7 @@ def test_involute():
     np.testing.assert_allclose(s.get_density(s.X_test[:64]), G["involute/density64"], rtol=1e-12)
 
 
-def test_uci_and_outlier_tables(tmp_path):
+def test_uci_tables(tmp_path):
     table = np.random.RandomState(int(G["uci_synth/table_seed"])).standard_normal((1000, 6))
     p = str(tmp_path / "data.npy")
     np.save(p, table)
@@ -75,64 +75,15 @@ def test_uci_and_outlier_tables(tmp_path):
     assert np.array_equal(s.X_val[:8], G["uci_synth/X_val_head"])
     assert s.X_train.shape == tuple(G["uci_synth/X_train_shape"])
     assert s.load_all()[0] is s.X_train
-    # ODDS layout: arr_0 data, arr_1 labels; no shuffle, tenths (util.py:22-33)
-    lab = (np.arange(1000) % 17 == 0).astype(int)
-    q = str(tmp_path / "data.npz")
-    np.savez(q, table, lab)
-    o = datasets.Outlier_sampler(q)
-    assert np.array_equal(o.X_test, table[-100:]) and np.array_equal(o.label_test, lab[-100:])
-    assert np.array_equal(o.X_val, table[-190:-100]) and o.X_train.shape == (810, 6)
-
-
-def test_hepmass_preprocessing(tmp_path):
-    """hepmass_sampler (util.py:73-118) on synthetic CSV files shaped like HEPMASS's: label column first, a trailing
-    extra column in the test file.  Parity unpinned (the reference's class is Python-2-only); the expectation is an
-    independent numpy computation of the same steps."""
-    rng = np.random.RandomState(3)
-    n_tr, n_te, nf = 400, 150, 6
-    tr = rng.standard_normal((n_tr, nf)).round(6)
-    te = rng.standard_normal((n_te, nf)).round(6)
-    lab_tr, lab_te = (rng.rand(n_tr) < 0.6).astype(float), (rng.rand(n_te) < 0.5).astype(float)
-    # feature 2: its smallest value occurs 9 times among the class-1 training rows -> removed;
-    # feature 4: a value that is NOT the smallest occurs 50 times -> kept (the reference only looks at the smallest)
-    pos = np.flatnonzero(lab_tr == 1)
-    tr[pos[:9], 2] = -7.5
-    tr[pos[10:60], 4] = 0.25
-    d = tmp_path / "datasets" / "HEPMASS"
-    d.mkdir(parents=True)
-    names = ["# label"] + ["f%d" % i for i in range(nf)]
-    with open(str(d / "1000_train.csv"), "w") as f:
-        f.write(",".join(names) + "\n")
-        for l, row in zip(lab_tr, tr):
-            f.write(",".join([repr(float(l))] + [repr(float(v)) for v in row]) + "\n")
-    with open(str(d / "1000_test.csv"), "w") as f:
-        f.write(",".join(names + ["mass"]) + "\n")
-        for l, row in zip(lab_te, te):
-            f.write(",".join([repr(float(l))] + [repr(float(v)) for v in row] + ["1000.0"]) + "\n")
-    s = datasets.hepmass_sampler(str(d))
-    a, b = tr[lab_tr == 1], te[lab_te == 1]
-    mu, sd = a.mean(axis=0), a.std(axis=0, ddof=1)
-    keep = [0, 1, 3, 4, 5]
-    a, b = ((a - mu) / sd)[:, keep], ((b - mu) / sd)[:, keep]
-    nv = int(0.1 * a.shape[0])
-    assert s.features_removed == [2]
-    np.testing.assert_allclose(s.X_train, a[:-nv], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(s.X_val, a[-nv:], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(s.X_test, b, rtol=1e-12, atol=1e-14)
-    assert s.nb_train == a.shape[0] - nv and s.load_all()[0] is s.X_train
-    ys, sd_y, scale = datasets.find_y_sampler("uci_HEPMASS", root=str(tmp_path))
-    assert (sd_y, scale) == (0.1, 0.1) and np.array_equal(ys.X_test, s.X_test)
 
 
 def test_factory_names_and_errors(tmp_path):
     assert set(datasets.SETTINGS) >= {"indep_gmm", "eight_octagon_gmm", "involute", "uci_AReM", "uci_CASP",
-                                      "uci_BANK", "uci_YPMSD", "uci_HEPMASS", "odds_Shuttle", "odds_Mammography",
-                                      "odds_ForestCover"}
-    # evaluate.py:173-181
-    assert datasets.SETTINGS["odds_Shuttle"][2:4] == (0.05, 1) and datasets.SETTINGS["odds_Mammography"][2:4] == (0.05, 0.5)
-    assert datasets.SETTINGS["odds_ForestCover"][2:4] == (0.1, 0.2)
-    with pytest.raises(ValueError):
-        datasets.find_y_sampler("no_such_set")
+                                      "uci_BANK", "uci_YPMSD", "uci_HEPMASS"}
+    assert datasets.SETTINGS["uci_HEPMASS"][:4] == (8, 21, 0.1, 0.1)
+    for name in ("no_such_set", "odds_Shuttle", "uci_HEPMASS"):      # the last two: out of scope
+        with pytest.raises(ValueError):
+            datasets.find_y_sampler(name)
     os.makedirs(str(tmp_path / "datasets" / "AReM"))
     np.save(str(tmp_path / "datasets" / "AReM" / "data.npy"), np.zeros((50, 6)))
     s, sd, scale = datasets.find_y_sampler("uci_AReM", root=str(tmp_path))

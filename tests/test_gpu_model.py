@@ -174,40 +174,6 @@ def test_cf_golden_vectors(name, tmp_path):
     assert np.abs(jac - f["jac_at_xhat"]).max() <= 1e-5 * np.abs(f["jac_at_xhat"]).max()
 
 
-def test_v2_evaluate_grid_caller(tmp_path):
-    """Roundtrip.evaluate (roundtrip.py:208-226): encoded data + IS and Laplace densities on the 2-D grid."""
-    if not os.path.exists("/dev/kfd"):
-        pytest.skip("no GPU on this machine")
-    params = dict(dataset="involute", output_dir=str(tmp_path), x_dim=2, z_dim=2, g_units=[512] * 10,
-                  e_units=[256] * 10, save_model=False, sd_x=0.4, scale=0.5, sample_size=500)
-    m = Roundtrip(params, timestamp="ev", random_seed=5)
-
-    class Sampler(object):
-        def load_all(self):
-            return np.random.RandomState(0).standard_normal((50, 2)).astype(np.float32)
-    m.data_sampler = Sampler()
-    n = 12
-    res = m.evaluate(7, n=n)
-    assert res["data_z"].shape == (50, 2)
-    assert np.array_equal(np.load("%s/data_z_at_7.npy" % m.save_dir), res["data_z"])
-    grid = np.vstack((res["v1"].ravel(), res["v2"].ravel())).T
-    assert grid.shape == (n * n, 2) and grid[:, 0].min() == -6 and grid[:, 0].max() == 5
-    want = m.estimate_px_with_IS(grid, sd_x=0.4, scale=0.5, sample_size=500, log=False).reshape(n, n)
-    assert np.array_equal(res["px_IS"], want)
-    assert np.array_equal(np.load("%s/2d_grid_IS_density_pre_at_7.npy" % m.save_dir), want)
-    assert np.array_equal(res["px_CF"], m.estimate_px_with_CF(grid, sd_x=0.4, log=False).reshape(n, n))
-    assert np.all(np.isfinite(res["px_CF"])) and np.all(res["px_IS"] >= 0)
-    # the samplers of roundtrip_amd.datasets return (X, Y) from load_all(), like util.py's: the data is the first item
-    from roundtrip_amd import datasets
-    params2 = dict(params, dataset="indep_gmm", sd_x=0.05)
-    m2 = Roundtrip(params2, timestamp="ev2", random_seed=5)
-    m2.data_sampler = datasets.GMM_indep_sampler(N=200, sd=0.1, dim=2, n_components=3, bound=1)
-    res2 = m2.evaluate(1, n=6)
-    X = m2.data_sampler.load_all()[0]
-    assert res2["data_z"].shape == X.shape and np.array_equal(res2["data_z"], m2.e_net(X))
-    assert res2["px_IS"].shape == (6, 6) and res2["v1"].min() == -1.5
-
-
 def test_reference_draws_mode_reproduces_the_single_threaded_reference(tmp_path, monkeypatch):
     """is_sampler = "numpy": numpy's legacy stream seeded with 0, consumed like sample_from_qx (main_density_est.py:267,
     310-318), scored on the GPU.  The oracle's statement-by-statement restatement of estimate_py_with_IS draws from the
