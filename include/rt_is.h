@@ -37,6 +37,7 @@ extern "C" {
 #define RT_ENOMEM        5
 #define RT_ETOOBIG       6   /* the call needs more than a fixed-size buffer holds (rt_is_estimate_dev_noalloc) */
 #define RT_ECOMM         7   /* RCCL could not be loaded, or one of its calls failed */
+#define RT_EBUSY         8   /* a per-GPU resource is in use by another context (rt_is_estimate_dev_noalloc's scratch array) */
 
 #define RT_MLP_G 0           /* generator  G: x (dx) -> y (dy)  : g_net, main_density_est.py:447 */
 #define RT_MLP_H 1           /* encoder    H: y (dy) -> x (dx)  : h_net / e_net, main_density_est.py:448 */
@@ -101,6 +102,39 @@ int rt_mlp_jacobian(rt_ctx* ctx, int which, const float* in, int64_t N, float* o
  * (main_density_est.py:320). */
 int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat);
 
+/* Laplace-approximation (closed-form) estimate of p(y[n]) for n < N: replaces estimate_py_with_CF
+ * (main_density_est.py:351-387; v2 estimate_px_with_CF, src/pyroundtrip/roundtrip.py:327-369) as a whole.  Needs G and H.
+ *   y   N x dy float64 query points        out  N float64:  log_flag 1: log p(y), 0: p(y)
+ * On the device, per query point: xhat = H((float)y) (:363), G(xhat) (:364) and the Jacobian J of G at xhat (:367,
+ * rt_mlp_jacobian's kernel), then in float64 (:365-384)
+ *   r = y - G(xhat);  A = J^T J;  b = J^T r;  Sigma_inv = I + A / sd_y^2;  mu = inv(Sigma_inv) (b / sd_y^2 - xhat);
+ *   c = |xhat|^2 + |r|^2 / sd_y^2 - mu^T Sigma_inv mu;
+ *   log p = -dy log(sqrt(2 pi) sd_y) + 0.5 log det inv(Sigma_inv) - 0.5 c                          (:382)
+ *   p     = 1 / (sqrt(2 pi) sd_y)^dy * sd_y^dy * sqrt(det inv(Sigma_inv)) * exp(-0.5 c)            (:384)
+ * (:384 carries an sd_y^dy factor :382 does not; both are reproduced as written).  The reference inverts Sigma_inv with
+ * LAPACK's LU and takes the determinant of the inverse; here the symmetric positive definite Sigma_inv is factored once
+ * (Cholesky), which gives the determinant and mu^T Sigma_inv mu = |L^-1 (b / sd_y^2 - xhat)|^2 directly: same value, agreeing
+ * with the reference's float64 formulas to ~1e-12 relative on well-conditioned points.  The Jacobians stay on the device.
+ * Limits: rt_mlp_jacobian's (hidden width <= 512), and dx*dx + dy + dx float64 values must fit the LDS (dx <= 128 does).
+ * rt_cf_estimate_dev: y_dev / out_dev are device pointers; asynchronous on the context's stream (rt_sync). */
+int rt_cf_estimate(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_flag, double* out);
+int rt_cf_estimate_dev(rt_ctx* ctx, const double* y_dev, int64_t N, double sd_y, int log_flag, double* out_dev);
+
+/* Mean and standard error of N float64 values on the device: the validation / test bookkeeping of train()
+ * (main_density_est.py:187-188 and :194-195: np.mean(py_est), np.std(py_est) / np.sqrt(len(py_est))).  The sums run in
+ * numpy's own order (np.add.reduce: buffers of 8192 elements, pairwise summation with eight partial sums per block of
+ * <= 128), the deviations are squared without fused multiply-add, division and square root are correctly rounded: the
+ * two results have the bits numpy returns for the same array.  N = 0 gives NaN, NaN (as numpy does).
+ *   rt_mean_stderr       values on the host (they are uploaded);  rt_mean_stderr_dev  values and out2 (mean, stderr) on
+ *                        the device, asynchronous on the context's stream
+ *   rt_is_estimate_summary   rt_is_estimate with log_flag = 1 plus the statistic of its N results, taken where they are
+ *                        (no second trip over the bus): what train() does with X_val / X_test at sample_size 2000. */
+int rt_mean_stderr(rt_ctx* ctx, const double* values, int64_t N, double* mean, double* stderr_out);
+int rt_mean_stderr_dev(rt_ctx* ctx, const double* values_dev, int64_t N, double* out2_dev);
+int rt_is_estimate_summary(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                           int64_t S, double sd_y, double scale, double df, uint64_t seed, double* out,
+                           double* mean, double* stderr_out);
+
 /* Importance-sampling estimate of p(y[n]) for n < N  (main_density_est.py:321-345).
  *   y      N x dy float64 query points          xhat   N x dx float32 proposal centres H(y)
  *   y_index_base  global index of y[0]: sample i of query point n is drawn from the counter-based
@@ -159,16 +193,22 @@ int rt_is_estimate_dev(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, 
                        int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
                        uint64_t seed, int log_flag, double* out_dev);
 
-/* rt_is_estimate_dev for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels, bit-identical results; it calls no
- * hipMalloc / hipFree / hipEventCreate (so rt_get_counters does not see its launches).  The one buffer the estimate
- * needs beyond its inputs and outputs — the per-pass (max v, sum exp(v - max)) pairs, 16 bytes per 64 samples (32 at
- * hidden width 1024) of every query point — lives in a file-scope __device__ array of RT_NOALLOC_SCRATCH_BYTES
- * (32 MiB) that every GPU the library runs on holds until the process ends.  A call whose pairs do not fit,
- *     N * ceil(S / 64) * 16  >  RT_NOALLOC_SCRATCH_BYTES        (e.g. N > 13 357 at S = 10 000)
- * is refused with RT_ETOOBIG and a message that names the largest N for this S; split it into several calls.  Every
- * pair a call reads it has written first, so the array needs no clearing between calls; all contexts on one GPU share
- * it, so calls that overlap on one GPU (two contexts, two threads) race — serialise them. */
+/* rt_is_estimate_dev for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc.
+ * NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels, bit-identical results; it calls no hipMalloc / hipFree /
+ * hipEventCreate (so rt_get_counters does not see its launches).  The one buffer the estimate needs beyond its inputs and
+ * outputs — the per-pass (max v, sum exp(v - max)) pairs, 16 bytes per pass of every query point — lives in a file-scope
+ * __device__ array of RT_NOALLOC_SCRATCH_BYTES (32 MiB) that every GPU the library runs on holds until the process
+ * ends.  A call whose pairs do not fit,
+ *     N * E * 16  >  RT_NOALLOC_SCRATCH_BYTES,   E = rt_is_pair_count(S)   (E = ceil(S / 64) unless the last S mod 64 <= 32
+ *                                                 samples are packed, 32-sample passes at hidden width 1024;
+ *                                                 e.g. N > 13 357 at S = 10 000, width 512),
+ * is refused with RT_ETOOBIG and a message that names the largest N for this S: the bound is on the WHOLE call's N
+ * (although its launches reuse the array block by block); split larger calls.  Every pair a call reads it has written
+ * first, so the array needs no clearing between calls.  All contexts on one GPU share the array: calls of one context are
+ * ordered by its stream; a call made while ANOTHER context's call on the same GPU is still outstanding is refused with
+ * RT_EBUSY (serialise the callers or rt_sync the other context first) rather than left to corrupt both results.
+ * (Not for HIP graph capture: the launches go to the context's own stream, and the launch sequence — the XCD-share
+ * update, a process's share-measuring first block — is decided at enqueue time.) */
 int rt_is_estimate_dev_noalloc(rt_ctx* ctx, const double* y_dev, const float* xhat_dev, int64_t N,
                                int64_t y_index_base, int64_t S, double sd_y, double scale, double df,
                                uint64_t seed, int log_flag, double* out_dev);
@@ -230,6 +270,9 @@ uint32_t rt_crc32c(const void* data, size_t n, uint32_t crc);
  * GPU library than this one).  rt_dev_free waits for the context's stream first; the copies are synchronous. */
 int rt_dev_alloc(rt_ctx* ctx, size_t bytes, void** out_dev);
 int rt_dev_free(rt_ctx* ctx, void* ptr_dev);
+/* Free and total device memory in bytes (hipMemGetInfo) on the context's device: lets a caller — and this repo's test of
+ * rt_is_estimate_dev_noalloc — see that a call allocated nothing. */
+int rt_dev_mem_info(rt_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int rt_memcpy_h2d(rt_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
 int rt_memcpy_d2h(rt_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
 

@@ -21,13 +21,15 @@ SYMBOLS = (
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
     "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs", "rt_is_estimate_dev_noalloc",
     "rt_philox4x32_10", "rt_crc32c", "rt_get_xcd_shares",
-    "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h",
+    "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_dev_mem_info",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
     "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
+    "rt_cf_estimate", "rt_cf_estimate_dev", "rt_mean_stderr", "rt_mean_stderr_dev", "rt_is_estimate_summary",
 )
 
 RT_ETOOBIG = 6
 RT_ECOMM = 7
+RT_EBUSY = 8
 RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 RT_COMM_ID_BYTES = 128
 
@@ -86,6 +88,7 @@ def load():
     lib.rt_crc32c.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
     lib.rt_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.rt_dev_free.argtypes = [vp, vp]
+    lib.rt_dev_mem_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.rt_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.rt_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.rt_comm_unique_id.argtypes = [vp]
@@ -96,6 +99,12 @@ def load():
     lib.rt_comm_all_gather_f64_dev.argtypes = [vp, vp, i64, vp]
     lib.rt_comm_all_reduce_max_f64.argtypes = [vp, vp, i64]
     lib.rt_comm_barrier.argtypes = [vp]
+    lib.rt_cf_estimate.argtypes = [vp, vp, i64, dbl, C.c_int, vp]
+    lib.rt_cf_estimate_dev.argtypes = [vp, vp, i64, dbl, C.c_int, vp]
+    lib.rt_mean_stderr.argtypes = [vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl)]
+    lib.rt_mean_stderr_dev.argtypes = [vp, vp, i64, vp]
+    lib.rt_is_estimate_summary.argtypes = [vp, vp, vp, i64, i64, i64, dbl, dbl, dbl, C.c_uint64, vp, C.POINTER(dbl),
+                                           C.POINTER(dbl)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("rt_last_error", "rt_crc32c"):
@@ -198,6 +207,41 @@ class Engine(object):
                                            int(seed), int(bool(log)), out.ctypes.data))
         return out
 
+    def is_estimate_summary(self, y, xhat, sample_size, sd_y, scale, df=1.0, seed=0, y_index_base=0):
+        """(log p(y) (N,), mean, standard error): rt_is_estimate with log=True and the statistic train() keeps of it
+        (main_density_est.py:186-188), reduced on the device in numpy's summation order."""
+        y, xhat, N, dx = self._points(y, xhat)
+        out = np.empty(N, dtype=np.float64)
+        mean, se = C.c_double(), C.c_double()
+        self._chk(self._lib.rt_is_estimate_summary(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
+                                                   int(sample_size), float(sd_y), float(scale), float(df), int(seed),
+                                                   out.ctypes.data, C.byref(mean), C.byref(se)))
+        return out, np.float64(mean.value), np.float64(se.value)
+
+    def mean_stderr(self, values):
+        """(np.mean(values), np.std(values) / np.sqrt(len(values))) computed on the device (rt_mean_stderr)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        mean, se = C.c_double(), C.c_double()
+        self._chk(self._lib.rt_mean_stderr(self._h, v.ctypes.data, v.size, C.byref(mean), C.byref(se)))
+        return np.float64(mean.value), np.float64(se.value)
+
+    def mean_stderr_dev(self, values_ptr, N, out2_ptr):
+        self._chk(self._lib.rt_mean_stderr_dev(self._h, values_ptr, int(N), out2_ptr))
+
+    def cf_estimate(self, y, sd_y, log=True):
+        """Laplace (closed-form) estimate for every row of y (N, dy): rt_cf_estimate, everything on the device."""
+        _, dy = self._g_dims()
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != dy:
+            raise ValueError("expected y of shape (N, %d), got %r" % (dy, y.shape))
+        out = np.empty(y.shape[0], dtype=np.float64)
+        self._chk(self._lib.rt_cf_estimate(self._h, y.ctypes.data, y.shape[0], float(sd_y), int(bool(log)),
+                                           out.ctypes.data))
+        return out
+
+    def cf_estimate_dev(self, y_ptr, N, sd_y, out_ptr, log=True):
+        self._chk(self._lib.rt_cf_estimate_dev(self._h, y_ptr, int(N), float(sd_y), int(bool(log)), out_ptr))
+
     def is_estimate_multi(self, y, xhat, sample_size, sd_ys, scale, df=1.0, seed=0, log=True, y_index_base=0):
         """One sampler + G pass scored for every sd in sd_ys; returns (len(sd_ys), N)."""
         y, xhat, N, dx = self._points(y, xhat)
@@ -291,6 +335,12 @@ class Engine(object):
     def dev_free(self, ptr):
         if ptr and getattr(self, "_h", None):
             self._chk(self._lib.rt_dev_free(self._h, ptr))
+
+    def dev_mem_info(self):
+        """(free, total) bytes of device memory on the engine's GPU."""
+        f, t = C.c_size_t(), C.c_size_t()
+        self._chk(self._lib.rt_dev_mem_info(self._h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     def to_device(self, arr):
         """A fresh device copy of a numpy array; returns the raw device address (free it with dev_free)."""

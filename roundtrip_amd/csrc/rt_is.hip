@@ -53,6 +53,11 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 constexpr int MAX_DEVICES = 64;
 void* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on HIP device i (nullptr: not looked up yet)
 std::mutex g_scratch_mu;
+// Who used device i's array last, and the event that context records behind its work on it (its own, made when the context
+// was: recording allocates nothing).  A second context asking for the array while that event has not completed is refused
+// (RT_EBUSY) instead of silently racing for the pairs.
+struct rt_ctx* g_scratch_owner[MAX_DEVICES];
+hipEvent_t g_scratch_event[MAX_DEVICES];
 // XCD shares (balance_update_kernel) a destroyed context of this process left for HIP device i: the relative speeds of a
 // chip's XCDs are a property of the chip, so the next context on it starts from them instead of from equal shares
 double g_bal_seed[MAX_DEVICES][9];
@@ -85,13 +90,14 @@ struct rt_ctx {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     HostMlp mlp[2];
-    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout, b_csend, b_crecv;
+    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout, b_csend, b_crecv, b_sum;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<const void*, int>> lds_allowed;   // kernels whose dynamic-LDS limit has been raised, and to what
     size_t events_used = 0;
     double ms_harvested = 0.0;              // durations already folded in by harvest_events()
     uint64_t launches_harvested = 0;
     void* scratch = nullptr;                // this device's copy of the `scratch` array (see above)
+    hipEvent_t scratch_done = nullptr;      // recorded behind every rt_is_estimate_dev_noalloc call (see g_scratch_owner)
     double* d_bal = nullptr;                // XCD balance: 9 cumulative shares (balance_update_kernel) ...
     unsigned long long* d_wg_times = nullptr;   // ... and the workgroups' start / end times of the last launch (2 x 1024)
     bool balance = true;                    // RT_IS_BALANCE=0 (read by rt_ctx_create) turns the balancing off
@@ -100,6 +106,7 @@ struct rt_ctx {
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
+    int64_t cf_block_points = 1 << 20;      // query points per block of the Laplace estimator (RT_CF_BLOCK_POINTS overrides)
     double flops_acc = 0.0;
     uint64_t evals_acc = 0;
     std::string err;
@@ -499,6 +506,83 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
     }
 }
 
+// The Laplace estimator for N query points whose float64 coordinates sit at y (device): per block of points, in stream
+// order, y -> float32 feed -> H forward (xhat) -> G forward + Jacobian at xhat (mlp_jvp_kernel) -> cf_finish_kernel.
+// The Jacobians never leave the device: a block's (<= 256 MB of float32, N_blk x dy x dx) is written by one kernel and
+// read by the next, which at the reference shapes is < 0.5 % of the Jacobian kernel's own time (YearPredictionMSD 20/90:
+// 7.2 KB per point against 40 rows x 4.8 MFLOP).  Buffers are sized once, before anything is enqueued.
+int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_flag, double* out) {
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    HostMlp& H = ctx->mlp[RT_MLP_H];
+    if (!G.set || !H.set) return fail(ctx, RT_ENOTSET, "the Laplace estimator needs both G (RT_MLP_G) and H (RT_MLP_H)");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (!(sd_y > 0.0) || !isfinite(sd_y)) return fail(ctx, RT_EINVAL, "sd_y must be positive and finite");
+    const int dx = G.args.in_dim, dy = G.args.out_dim;
+    if (H.args.in_dim != dy || H.args.out_dim != dx)
+        return fail(ctx, RT_EINVAL, "H must map G's output dim to G's input dim");
+    if (G.nst != 2) return fail(ctx, RT_EUNSUPPORTED, "Jacobian needs hidden width <= 512 (64-column passes)");
+    const int lds = (dx * dx + dy + dx) * (int)sizeof(double);
+    if (lds > LDS_MAX) return fail(ctx, RT_EUNSUPPORTED, "Laplace estimator: dx x dx float64 matrix does not fit the LDS");
+    if (N == 0) return RT_OK;
+    int64_t per = (int64_t)((256ull << 20) / ((size_t)dx * dy * sizeof(float)));
+    if (per > ctx->cf_block_points) per = ctx->cf_block_points;
+    per &= ~(int64_t)31;                       // whole 32-row blocks of the Jacobian kernel
+    if (per < 32) per = 32;
+    if (per > N) per = N;
+    int rc = ensure(ctx, ctx->b_in, (size_t)per * dy * sizeof(float)); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_xhat, (size_t)per * dx * sizeof(float)); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_fout, (size_t)per * dy * (1 + (size_t)dx) * sizeof(float)); if (rc) return rc;
+    HIPCHK(ctx, allow_lds(ctx, (const void*)cf_finish_kernel, lds));
+    const double PI = 3.14159265358979323846;
+    // the constants of :382 / :384 as the reference's Python evaluates them
+    const double c0 = -(double)dy * log(sqrt(2.0 * PI) * sd_y);
+    const double lin_scale = 1.0 / pow(sqrt(2.0 * PI) * sd_y, (double)dy) * pow(sd_y, (double)dy);
+    float* y32 = (float*)ctx->b_in.p;
+    float* xhat = (float*)ctx->b_xhat.p;
+    float* gy = (float*)ctx->b_fout.p;
+    float* J = gy + (size_t)per * dy;
+    for (int64_t n0 = 0; n0 < N; n0 += per) {
+        const int64_t nb = (N - n0 < per) ? N - n0 : per;
+        const int64_t cnt = nb * dy;
+        hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           y + n0 * dy, cnt, y32);
+        HIPCHK(ctx, hipGetLastError());
+        rc = fwd_enqueue(ctx, RT_MLP_H, y32, nb, xhat); if (rc) return rc;
+        rc = jvp_enqueue(ctx, RT_MLP_G, xhat, nb, gy, J); if (rc) return rc;
+        const int64_t gmax = (int64_t)ctx->cu_count * 16;
+        hipLaunchKernelGGL(cf_finish_kernel, dim3((unsigned)(nb < gmax ? nb : gmax)), dim3(64), lds, ctx->stream,
+                           y + n0 * dy, (const float*)xhat, (const float*)gy, (const float*)J, nb, dx, dy, sd_y * sd_y, c0,
+                           lin_scale, log_flag, out + n0);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+// (mean, standard error) of the N float64 values at v (device) into out2 (device, 2 doubles), in numpy's summation
+// order (np_chunk_sum_kernel).  b_sum holds the per-buffer sums followed by the two results when out2 is NULL.
+int mean_stderr_enqueue(rt_ctx* ctx, const double* v, int64_t N, double* out2) {
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    const int64_t nchunks = (N + NP_BUF - 1) / NP_BUF;
+    const int rc = ensure(ctx, ctx->b_sum, (size_t)(nchunks + 2) * sizeof(double));
+    if (rc) return rc;
+    double* cs = (double*)ctx->b_sum.p;
+    if (!out2) out2 = cs + nchunks;
+    for (int stage = 0; stage < 2; ++stage) {
+        if (nchunks > 0) {
+            if (stage == 0)
+                hipLaunchKernelGGL(np_chunk_sum_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, v, N,
+                                   (const double*)nullptr, cs);
+            else
+                hipLaunchKernelGGL(np_chunk_sum_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, v, N,
+                                   (const double*)out2, cs);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(np_reduce_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)cs, nchunks, N, stage, out2);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -520,6 +604,10 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (const char* v = getenv("RT_IS_MAX_LAUNCH_EVALS")) {
         const long long n = atoll(v);
         if (n > 0) ctx->max_launch_evals = n;
+    }
+    if (const char* v = getenv("RT_CF_BLOCK_POINTS")) {
+        const long long n = atoll(v);
+        if (n > 0) ctx->cf_block_points = n;
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_EHIP, hipGetErrorString(e)); }
@@ -562,6 +650,13 @@ int rt_ctx_create(int device, rt_ctx** out) {
             g_scratch_ptr[device] = ptr;
         }
         ctx->scratch = g_scratch_ptr[device];
+        e = hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipFree(ctx->d_bal);
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(nullptr, RT_EHIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+        }
     }
     *out = ctx;
     return RT_OK;
@@ -575,7 +670,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     free_mlp(ctx->mlp[0]);
     free_mlp(ctx->mlp[1]);
     DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout,
-                      &ctx->b_csend, &ctx->b_crecv};
+                      &ctx->b_csend, &ctx->b_crecv, &ctx->b_sum};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->d_bal) {
         double cum[9];
@@ -588,6 +683,11 @@ int rt_ctx_destroy(rt_ctx* ctx) {
         (void)hipFree(ctx->d_bal);
     }
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->scratch_done) {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);          // (the stream has been drained above)
+        if (ctx->device < MAX_DEVICES && g_scratch_owner[ctx->device] == ctx) g_scratch_owner[ctx->device] = nullptr;
+        (void)hipEventDestroy(ctx->scratch_done);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -748,9 +848,60 @@ int rt_encode(rt_ctx* ctx, const float* y, int64_t N, float* xhat) {
     return rt_mlp_forward(ctx, RT_MLP_H, y, N, xhat);
 }
 
+int rt_cf_estimate_dev(rt_ctx* ctx, const double* y_dev, int64_t N, double sd_y, int log_flag, double* out_dev) {
+    if (!ctx) return RT_EINVAL;
+    if (N > 0 && (!y_dev || !out_dev)) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return cf_enqueue(ctx, y_dev, N, sd_y, log_flag, out_dev);
+}
+
+int rt_cf_estimate(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_flag, double* out) {
+    if (!ctx) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "the Laplace estimator needs both G (RT_MLP_G) and H (RT_MLP_H)");
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if (N > 0 && (!y || !out)) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t yb = (size_t)N * G.args.out_dim * sizeof(double), ob = (size_t)N * sizeof(double);
+    if (N > 0) {
+        int rc = ensure(ctx, ctx->b_y, yb); if (rc) return rc;
+        rc = ensure(ctx, ctx->b_out, ob); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->b_y.p, y, yb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int rc = cf_enqueue(ctx, (const double*)ctx->b_y.p, N, sd_y, log_flag, (double*)ctx->b_out.p);
+    if (rc || N == 0) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_mean_stderr_dev(rt_ctx* ctx, const double* values_dev, int64_t N, double* out2_dev) {
+    if (!ctx) return RT_EINVAL;
+    if ((N > 0 && !values_dev) || !out2_dev) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return mean_stderr_enqueue(ctx, values_dev, N, out2_dev);
+}
+
+int rt_mean_stderr(rt_ctx* ctx, const double* values, int64_t N, double* mean, double* stderr_out) {
+    if (!ctx) return RT_EINVAL;
+    if (N < 0) return fail(ctx, RT_EINVAL, "N < 0");
+    if ((N > 0 && !values) || !mean || !stderr_out) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->b_out, (size_t)(N > 0 ? N : 1) * sizeof(double)); if (rc) return rc;
+    if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->b_out.p, values, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = mean_stderr_enqueue(ctx, (const double*)ctx->b_out.p, N, nullptr); if (rc) return rc;
+    double res[2];
+    const int64_t nchunks = (N + NP_BUF - 1) / NP_BUF;
+    HIPCHK(ctx, hipMemcpyAsync(res, (const double*)ctx->b_sum.p + nchunks, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *mean = res[0];
+    *stderr_out = res[1];
+    return RT_OK;
+}
+
 static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double* xs, int64_t N,
                    int64_t y_index_base, int64_t S, int n_sd, const double* sd_ys, double scale, double df,
-                   uint64_t seed, int log_flag, double* out, bool given) {
+                   uint64_t seed, int log_flag, double* out, bool given, double* mean_se = nullptr) {
     if (!ctx) return RT_EINVAL;
     HostMlp& G = ctx->mlp[RT_MLP_G];
     if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
@@ -778,7 +929,27 @@ static int is_host(rt_ctx* ctx, const double* y, const float* xhat, const double
                     S, n_sd, sd_ys, scale, df, seed, log_flag, (double*)ctx->b_out.p);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, (size_t)N * n_sd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mean_se) {   // the statistic of the results where they are: no second trip over the bus (n_sd == 1 here)
+        rc = mean_stderr_enqueue(ctx, (const double*)ctx->b_out.p, N, nullptr); if (rc) return rc;
+        const int64_t nchunks = (N + NP_BUF - 1) / NP_BUF;
+        HIPCHK(ctx, hipMemcpyAsync(mean_se, (const double*)ctx->b_sum.p + nchunks, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_is_estimate_summary(rt_ctx* ctx, const double* y, const float* xhat, int64_t N, int64_t y_index_base,
+                           int64_t S, double sd_y, double scale, double df, uint64_t seed, double* out,
+                           double* mean, double* stderr_out) {
+    if (!ctx) return RT_EINVAL;
+    if (!mean || !stderr_out) return fail(ctx, RT_EINVAL, "NULL argument");
+    if (N <= 0) return fail(ctx, RT_EINVAL, "rt_is_estimate_summary needs N >= 1");
+    double ms[2];
+    const int rc = is_host(ctx, y, xhat, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, 1, out, false, ms);
+    if (rc) return rc;
+    *mean = ms[0];
+    *stderr_out = ms[1];
     return RT_OK;
 }
 
@@ -817,7 +988,25 @@ int rt_is_estimate_dev_noalloc(rt_ctx* ctx, const double* y_dev, const float* xh
     if (!ctx->scratch) return fail(ctx, RT_EUNSUPPORTED, "no scratch array on this device (HIP device index >= 64)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const PairBuf pb{(double*)ctx->scratch, (size_t)RT_NOALLOC_SCRATCH_BYTES, false};
-    return is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev, &pb);
+    // one context at a time per GPU: the array is shared.  Calls of ONE context are ordered by its stream; another
+    // context's call is refused while the last user's work on the array is still outstanding (no allocation: the event
+    // is the owner's own, made with its context).  The lock covers enqueue + record, so the hand-over cannot interleave.
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    rt_ctx* owner = g_scratch_owner[ctx->device];
+    if (owner && owner != ctx) {
+        const hipError_t q = hipEventQuery(g_scratch_event[ctx->device]);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return fail(ctx, RT_EBUSY, "rt_is_estimate_dev_noalloc: another context's call on this GPU's scratch array is "
+                                       "still outstanding (the array is shared per GPU: serialise the callers, or rt_sync the other context first)");
+        }
+        if (q != hipSuccess) return fail(ctx, RT_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    }
+    g_scratch_owner[ctx->device] = ctx;
+    g_scratch_event[ctx->device] = ctx->scratch_done;
+    const int rc = is_enqueue(ctx, y_dev, xhat_dev, nullptr, N, y_index_base, S, 1, &sd_y, scale, df, seed, log_flag, out_dev, &pb);
+    HIPCHK(ctx, hipEventRecord(ctx->scratch_done, ctx->stream));
+    return rc;
 }
 
 int rt_is_pair_count(rt_ctx* ctx, int64_t S, int64_t* E) {
@@ -1050,6 +1239,13 @@ int rt_dev_alloc(rt_ctx* ctx, size_t bytes, void** out) {
         *out = nullptr;
         return fail(ctx, RT_ENOMEM, "hipMalloc failed");
     }
+    return RT_OK;
+}
+
+int rt_dev_mem_info(rt_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return RT_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemGetInfo(free_bytes, total_bytes));
     return RT_OK;
 }
 

@@ -484,6 +484,164 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Laplace (closed-form) estimator, the part after the three network evaluations (main_density_est.py:365-384; v2
+// roundtrip.py:341-366).  One wave per query point; everything in float64, like the reference's numpy:
+//   r = y - G(xhat),  rt_error = |r|^2                                                      (:365)
+//   A = J^T J,  b = J^T r                                                                   (:371, :373)
+//   Sigma_inv = I + A / sd^2,  Sigma = inv(Sigma_inv)                                       (:375-376)
+//   mu = Sigma (b / sd^2 - xhat)                                                            (:378)
+//   c(y) = |xhat|^2 + rt_error / sd^2 - mu^T Sigma_inv mu                                   (:380)
+//   log p = -dy log(sqrt(2 pi) sd) + 0.5 log det Sigma - 0.5 c                              (:382)
+//   p     = 1 / (sqrt(2 pi) sd)^dy * sd^dy * sqrt(det Sigma) * exp(-0.5 c)                  (:384, extra sd^dy kept)
+// Sigma_inv is symmetric positive definite (eigenvalues >= 1), so instead of the reference's LU-based inv / det the
+// wave factors it once, Sigma_inv = L L^T (Cholesky, in LDS): det Sigma = prod 1 / L_kk^2, and with w = L^-1 (b / sd^2 -
+// xhat) (forward substitution, fused into the factorisation's column loop) mu^T Sigma_inv mu = |w|^2 — the same numbers
+// without ever forming Sigma or mu.  J arrives as the float32 values get_jacobian returns (:254: a float64 container of
+// float32 results), G(xhat) and xhat likewise (:225, :240).
+// lin_scale = 1 / (sqrt(2 pi) sd)^dy * sd^dy and c0 = -dy log(sqrt(2 pi) sd) come from the host.
+// LDS: dx*dx + dy + dx doubles.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cf_finish_kernel(const double* y, const float* xhat, const float* gy, const float* J,
+                                                       int64_t N, int dx, int dy, double sd2, double c0, double lin_scale,
+                                                       int log_flag, double* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* M = (double*)smem;          // dx x dx, lower triangle used
+    double* r = M + dx * dx;            // dy
+    double* w = r + dy;                 // dx
+    const int lane = threadIdx.x;
+    for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+        const float* Jn = J + (size_t)n * dy * dx;
+        double se = 0.0, xx = 0.0;
+        for (int i = lane; i < dy; i += 64) {
+            const double t = y[n * dy + i] - (double)gy[n * dy + i];
+            r[i] = t;
+            se += t * t;
+        }
+        for (int d = lane; d < dx; d += 64) { const double t = (double)xhat[n * dx + d]; xx += t * t; }
+        se = wave_sum(se);
+        xx = wave_sum(xx);
+        __syncthreads();
+        for (int p = lane; p < dx * dx; p += 64) {
+            const int d1 = p / dx, d2 = p - d1 * dx;
+            double a = 0.0;
+            for (int i = 0; i < dy; ++i) a = fma((double)Jn[i * dx + d1], (double)Jn[i * dx + d2], a);
+            M[p] = ((d1 == d2) ? 1.0 : 0.0) + a / sd2;
+        }
+        for (int d = lane; d < dx; d += 64) {
+            double b = 0.0;
+            for (int i = 0; i < dy; ++i) b = fma((double)Jn[i * dx + d], r[i], b);
+            w[d] = b / sd2 - (double)xhat[n * dx + d];
+        }
+        __syncthreads();
+        // right-looking Cholesky of the lower triangle, column by column, with the forward substitution riding along
+        double sum_log_l = 0.0, prod_l = 1.0, quad = 0.0;     // wave-uniform
+        for (int k = 0; k < dx; ++k) {
+            const double l = sqrt(M[k * dx + k]);
+            const double wk = w[k] / l;
+            sum_log_l += log(l);
+            prod_l *= l;
+            quad += wk * wk;
+            for (int i = k + 1 + lane; i < dx; i += 64) {
+                const double m = M[i * dx + k] / l;
+                M[i * dx + k] = m;
+                w[i] -= m * wk;
+            }
+            __syncthreads();
+            const int m_ = dx - k - 1;
+            for (int p = lane; p < m_ * m_; p += 64) {
+                const int a_ = p / m_, b_ = p - a_ * m_;
+                if (b_ <= a_) M[(k + 1 + a_) * dx + (k + 1 + b_)] -= M[(k + 1 + a_) * dx + k] * M[(k + 1 + b_) * dx + k];
+            }
+            __syncthreads();
+        }
+        const double c = xx + se / sd2 - quad;
+        if (lane == 0) out[n] = log_flag ? c0 - sum_log_l - 0.5 * c : lin_scale * (1.0 / prod_l) * exp(-0.5 * c);
+        __syncthreads();      // r / w / M are rewritten for the next point
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Mean and standard error of N float64 values — the validation / test bookkeeping of train()
+// (main_density_est.py:187-188, 194-195: np.mean(py_est), np.std(py_est) / np.sqrt(len(py_est))) — on the device, in
+// NUMPY'S OWN SUMMATION ORDER, so that the two numbers carry the bits numpy gives on the same array:
+//   np.add.reduce over a contiguous float64 array walks it in buffers of 8192 elements (np.getbufsize()), adds each
+//   buffer's pairwise sum to a running total that starts at 0, and the pairwise sum of n elements is: n < 8: a plain
+//   loop from 0; n <= 128: eight strided partial sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail
+//   one by one; else the sum of the first n2 = n/2 - (n/2) % 8 elements plus the sum of the rest, recursively.
+//   np.mean = that sum / N; np.std = sqrt(sum((x - mean)^2) / N) with the subtraction and the product rounded
+//   separately (no fused multiply-add).
+// np_chunk_sum_kernel: one workgroup per buffer; thread h is node h of the buffer's recursion tree in heap order (at most
+// 255 nodes: depth <= 7), leaves sum their elements, inner nodes are combined level by level.  SQDEV: the elements are
+// (v - *mean_p)^2.  np_reduce_kernel (one thread) adds the buffers' sums in order and finishes the statistic.
+// ----------------------------------------------------------------------------------------------
+constexpr int NP_BUF = 8192;     // numpy's default ufunc buffer size, in elements
+template <bool SQDEV>
+__global__ __launch_bounds__(256) void np_chunk_sum_kernel(const double* v, int64_t N, const double* mean_p,
+                                                           double* chunk_sums) {
+    __shared__ double val[256];
+    const int64_t lo = (int64_t)blockIdx.x * NP_BUF;
+    const int m = (int)((N - lo < NP_BUF) ? N - lo : NP_BUF);
+    const int h = threadIdx.x;
+    const int d = 31 - __clz(h + 1), i = h + 1 - (1 << d);      // depth and index within the level
+    int off = 0, len = m;
+    bool real = h < 255;
+    for (int b = d - 1; b >= 0 && real; --b) {
+        if (len <= 128) { real = false; break; }                  // an ancestor is a leaf: this node does not exist
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if ((i >> b) & 1) { off += n2; len -= n2; } else len = n2;
+    }
+    const double mean = SQDEV ? *mean_p : 0.0;
+    auto at = [&](int k) {
+        const double x = v[lo + off + k];
+        if (!SQDEV) return x;
+        const double t = __dsub_rn(x, mean);
+        return __dmul_rn(t, t);
+    };
+    if (real && len <= 128) {
+        double res;
+        if (len < 8) {
+            res = 0.0;
+            for (int k = 0; k < len; ++k) res = __dadd_rn(res, at(k));
+        } else {
+            double r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = at(j);
+            int k = 8;
+            for (; k < len - (len % 8); k += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], at(k + j));
+            }
+            res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                            __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+            for (; k < len; ++k) res = __dadd_rn(res, at(k));
+        }
+        val[h] = res;
+    }
+    __syncthreads();
+    for (int dd = 6; dd >= 0; --dd) {
+        if (real && d == dd && len > 128) val[h] = __dadd_rn(val[2 * h + 1], val[2 * h + 2]);
+        __syncthreads();
+    }
+    if (h == 0) chunk_sums[blockIdx.x] = val[0];
+}
+// stage 0: out2[0] = mean.  stage 1 (chunk_sums of the squared deviations): out2[1] = sqrt(sum / N) / sqrt(N).
+__global__ void np_reduce_kernel(const double* chunk_sums, int64_t nchunks, int64_t N, int stage, double* out2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double res = 0.0;
+    for (int64_t c = 0; c < nchunks; ++c) res = __dadd_rn(res, chunk_sums[c]);
+    const double q = __ddiv_rn(res, (double)N);
+    if (stage == 0) out2[0] = q;
+    else out2[1] = __ddiv_rn(__dsqrt_rn(q), __dsqrt_rn((double)N));
+}
+
+// float32 feed of a float64 array: what the reference does when it hands y_points to the TF placeholder (:247)
+__global__ void cast_f64_f32_kernel(const double* in, int64_t n, float* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (float)in[t];
+}
+
 __global__ void draw_samples_kernel(SamplerArgs sa, const float* xhat, int64_t N, int64_t y_index_base,
                                     int64_t S, int dx, float* xs) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

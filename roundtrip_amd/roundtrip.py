@@ -158,46 +158,18 @@ class _IsModelBase(object):
         return out.astype(np.float64), J.astype(np.float64)
 
     def _estimate_cf(self, points, sd, log):
-        """main_density_est.py:351-387 (v2: roundtrip.py:327-369).  The three network evaluations — H(y),
-        G(H(y)) and the Jacobian of G at H(y) — run on the GPU; the x_dim x x_dim linear algebra is the
-        reference's float64 numpy, batched over the points instead of mapped one by one."""
+        """main_density_est.py:351-387 (v2: roundtrip.py:327-369), everything on the GPU (rt_cf_estimate): H(y), G(H(y)),
+        the Jacobian of G at H(y), and the float64 x_dim x x_dim algebra per query point; the Jacobians never leave the
+        device."""
         g_net = self._nets()[0][1]
         points = np.asarray(points)
         assert points.ndim == 2 and points.shape[-1] == g_net.output_dim
         points = np.ascontiguousarray(points, dtype=np.float64)
         self._sync_weights()
         eng = self.engine
-        x_dim, y_dim = g_net.input_dim, g_net.output_dim
-
-        # query points are independent: evaluated in sub-blocks of <= 64 MB of float64 Jacobians (1M YPMSD points would
-        # otherwise hold 14 GB of them at once); the sub-block size changes no result
-        cb = max(1, (64 << 20) // (x_dim * y_dim * 8))
 
         def block(pts, base):
-            if pts.shape[0] > cb:
-                return np.concatenate([sub_block(pts[i:i + cb]) for i in range(0, pts.shape[0], cb)])
-            return sub_block(pts)
-
-        def sub_block(pts):
-            x_ = eng.mlp_forward(_lib.RT_MLP_H, pts.astype(np.float32)).astype(np.float64)          # :363
-            y__, jacob_mat = self._jacobian(x_)                                                      # :364, :367
-            resid = pts - y__
-            rt_error = np.sum(resid ** 2, axis=1)                                                    # :365
-            # stacked matmul = the reference's np.dot per point (one BLAS call per matrix: the same bits, and 15 x faster
-            # than an einsum over 90 x 20 Jacobians)
-            jac_t = jacob_mat.transpose((0, 2, 1))                                                   # :369
-            A = np.matmul(jac_t, jacob_mat)                                                          # :371
-            b = np.matmul(jac_t, resid[:, :, None])[:, :, 0]                                         # :373
-            Sigma_inv = np.eye(x_dim)[None, :, :] + A / sd ** 2                                      # :376
-            Sigma = np.linalg.inv(Sigma_inv)                                                         # :375
-            mu = np.matmul(Sigma, (b / sd ** 2 - x_)[:, :, None])[:, :, 0]                           # :378
-            quad = np.matmul(np.matmul(mu[:, None, :], Sigma_inv), mu[:, :, None])[:, 0, 0]          # z.T.dot(w).dot(z)
-            c_y = np.sum(x_ ** 2, axis=1) + rt_error / sd ** 2 - quad                                # :380
-            det = np.linalg.det(Sigma)
-            if log:
-                return -y_dim * np.log(np.sqrt(2 * np.pi) * sd) + 0.5 * np.log(det) - 0.5 * c_y      # :382
-            # :384 — the reference's log=False branch carries an extra sd**y_dim factor; kept as written
-            return 1. / (np.sqrt(2 * np.pi) * sd) ** y_dim * sd ** y_dim * np.sqrt(det) * np.exp(-0.5 * c_y)
+            return eng.cf_estimate(pts, sd, log=log)
 
         if self.shard and dist.active():
             return dist.sharded_map(points, block, device=eng.device)
@@ -412,11 +384,27 @@ class RoundtripModel(_IsModelBase):
 
     def likelihood_summary(self, y_points, epoch, sd_y, scale, sample_size=2000, log_file=None, save=False):
         """The validation / test bookkeeping of train() (main_density_est.py:186-196): mean log-likelihood and its
-        standard error; appends '<epoch>\t<mean>\t<stderr>' to log_file (an open file) when given."""
-        py_est = self.estimate_py_with_IS(y_points, epoch, sd_y=sd_y, scale=scale, sample_size=sample_size,
-                                          log=True, save=save)
-        average_likelihood = np.mean(py_est)
-        sd_likelihood = np.std(py_est) / np.sqrt(len(py_est))
+        standard error, reduced on the device in numpy's summation order (rt_is_estimate_summary / rt_mean_stderr: the
+        bits of np.mean(py_est) and np.std(py_est) / np.sqrt(len(py_est))); appends '<epoch>\t<mean>\t<stderr>' to
+        log_file (an open file) when given."""
+        y_points = np.asarray(y_points)
+        assert y_points.ndim == 2 and y_points.shape[-1] == self.y_dim
+        eng = self.engine
+        if self.is_sampler == "philox" and not (self.shard and dist.active()) and y_points.shape[0] > 0:
+            pts = np.ascontiguousarray(y_points, dtype=np.float64)
+            self._sync_weights()
+            centres = eng.mlp_forward(_lib.RT_MLP_H, pts.astype(np.float32))
+            py_est, average_likelihood, sd_likelihood = eng.is_estimate_summary(
+                pts, centres, sample_size, sd_y, scale, df=self.df, seed=self.is_seed)
+            if save:
+                if not os.path.exists(self.save_dir):
+                    os.makedirs(self.save_dir)
+                np.save('%s/py_est_at_epoch%d.npy' % (self.save_dir, epoch), py_est)
+        else:
+            # sharded over ranks (or the reference-draws mode): the gathered results go back to the device for the statistic
+            py_est = self.estimate_py_with_IS(y_points, epoch, sd_y=sd_y, scale=scale, sample_size=sample_size,
+                                              log=True, save=save)
+            average_likelihood, sd_likelihood = eng.mean_stderr(py_est)
         if log_file is not None:
             log_file.write('%d\t%f\t%f\n' % (epoch, average_likelihood, sd_likelihood))
         return average_likelihood, sd_likelihood

@@ -1,0 +1,171 @@
+"""GPU tests of the Laplace (closed-form) estimator on the device (rt_cf_estimate: estimate_py_with_CF,
+main_density_est.py:351-387) and of the device-side mean / standard error (rt_mean_stderr: :187-188), through the C ABI.
+
+Tolerances: the float64 algebra against the reference's formulas evaluated by numpy ON THE SAME Jacobian (the C oracle's,
+kernel summation order, bit-identical to the GPU's): 1e-9 relative; against the statement-by-statement numpy restatement
+of the whole estimator (natural summation order, float32 rounding of G and J differs): 1e-4 relative (north_star);
+mean / standard error against numpy: the same bits."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, is_ref
+from roundtrip_amd import _lib
+
+from test_oracle import GOLDEN, golden_nets
+
+pytestmark = pytest.mark.gpu
+
+G, H = _lib.RT_MLP_G, _lib.RT_MLP_H
+DIMS = [(2, 2), (3, 6), (5, 9), (8, 17), (8, 21), (20, 90)]
+
+
+def cf_reference_formulas(y, x_, y__, J, sd, log):
+    """main_density_est.py:365-384 literally (np.dot, np.linalg.inv, np.linalg.det), point by point, from given
+    network outputs."""
+    dx, dy = x_.shape[1], y.shape[1]
+    out = []
+    for n in range(len(y)):
+        r = y[n] - y__[n]
+        A = np.dot(J[n].T, J[n])
+        b = np.dot(J[n].T, r)
+        Sigma = np.linalg.inv(np.eye(dx) + A / sd ** 2)
+        Sigma_inv = np.eye(dx) + A / sd ** 2
+        mu = Sigma.dot(b / sd ** 2 - x_[n])
+        c = np.sum(x_[n] ** 2) + np.sum(r ** 2) / sd ** 2 - mu.T.dot(Sigma_inv).dot(mu)
+        if log:
+            out.append(-dy * np.log(np.sqrt(2 * np.pi) * sd) + 0.5 * np.log(np.linalg.det(Sigma)) - 0.5 * c)
+        else:
+            out.append(1. / (np.sqrt(2 * np.pi) * sd) ** dy * sd ** dy * np.sqrt(np.linalg.det(Sigma)) * np.exp(-0.5 * c))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("dx,dy", DIMS)
+def test_cf_estimate_against_the_reference_formulas(engine, make_nets, dx, dy):
+    gw, gb, hw, hb = make_nets(dx, dy)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    og, oh = c_oracle.OracleMlp(gw, gb), c_oracle.OracleMlp(hw, hb)
+    rng = np.random.RandomState(31 * dx + dy)
+    y = rng.standard_normal((77, dy)) * 0.4
+    x_ = oh.forward(y.astype(np.float32), c_oracle.ORDER_KERNEL, nthreads=8).astype(np.float64)
+    y__, J = og.jacobian(x_, c_oracle.ORDER_KERNEL, nthreads=8)
+    y__, J = y__.astype(np.float64), J.astype(np.float64)
+    for sd in (0.5, 0.1):
+        got = engine.cf_estimate(y, sd, log=True)
+        assert got.shape == (77,) and got.dtype == np.float64 and np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, cf_reference_formulas(y, x_, y__, J, sd, True), rtol=1e-9)
+        lin = engine.cf_estimate(y, sd, log=False)
+        want_lin = cf_reference_formulas(y, x_, y__, J, sd, False)
+        ok = want_lin > 1e-300
+        np.testing.assert_allclose(lin[ok], want_lin[ok], rtol=1e-9)
+        assert np.all(lin[~ok] <= 1e-300)
+        # the whole estimator restated in numpy (natural summation order): north_star tolerance
+        want = is_ref.estimate_py_with_CF(is_ref.DenseNet(gw, gb), is_ref.DenseNet(hw, hb), y, sd_y=sd, log=True)
+        np.testing.assert_allclose(got, want, rtol=1e-4)
+
+
+def test_cf_estimate_dev_blocks_and_edges(make_nets, monkeypatch):
+    """Device pointers; a call split into blocks of 32 / 64 points gives the one-block bits; N = 0, 1, 33; errors."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    gw, gb, hw, hb = make_nets(5, 9)
+    rng = np.random.RandomState(9)
+    y = rng.standard_normal((150, 9)) * 0.5
+    res = {}
+    for blk in (None, "32", "64"):
+        if blk:
+            monkeypatch.setenv("RT_CF_BLOCK_POINTS", blk)
+        eng = _lib.Engine(0)
+        try:
+            eng.set_mlp(G, gw, gb)
+            with pytest.raises(_lib.RtError):
+                eng.cf_estimate(y, 0.1)                                  # H missing
+            eng.set_mlp(H, hw, hb)
+            y_d = eng.to_device(y)
+            o_d = eng.to_device(np.full(150, -1.0))
+            eng.cf_estimate_dev(y_d, 150, 0.1, o_d, log=True)
+            eng.sync()
+            res[blk] = eng.from_device(o_d, (150,), np.float64)
+            assert np.array_equal(res[blk], eng.cf_estimate(y, 0.1))
+            for n in (1, 33):
+                assert np.array_equal(eng.cf_estimate(y[:n], 0.1), res[blk][:n])
+            assert eng.cf_estimate(np.zeros((0, 9)), 0.1).shape == (0,)
+            with pytest.raises(_lib.RtError):
+                eng.cf_estimate(y, -1.0)
+            with pytest.raises(ValueError):
+                eng.cf_estimate(y[:, :4], 0.1)
+            eng.dev_free(y_d)
+            eng.dev_free(o_d)
+        finally:
+            eng.close()
+    assert np.array_equal(res[None], res["32"]) and np.array_equal(res[None], res["64"])
+
+
+@pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
+def test_cf_estimate_golden(engine, name):
+    f = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gw, gb, hw, hb = golden_nets(f)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    np.testing.assert_allclose(engine.cf_estimate(f["y"], float(f["sd"]), log=True), f["cf_log_est"], rtol=1e-4)
+
+
+def test_cf_linear_generator_known_answer_on_gpu(engine):
+    """A generator built to be exactly linear, G(x) = x A + b: the Laplace approximation is then exact whatever point
+    it expands at, p(y) = N(y; b, A^T A + sd^2 I) (tests/test_oracle.py::test_cf_linear_generator_known_answer states
+    the same for the CPU restatement); the log=False branch carries the reference's extra sd^dy factor (:384)."""
+    from test_oracle import gaussian_logpdf, linear_g
+    from conftest import glorot
+    dx, dy, sd = 2, 3, 0.4
+    A = np.array([[1.0, 0.5, -0.25], [0.3, -0.7, 0.9]], np.float32)
+    b = np.array([0.1, -0.2, 0.3], np.float32)
+    gw, gb = linear_g(dx, dy, 128, 3, A, b)
+    hw, hb = glorot([dy, 128, 128, dx], 17, 18)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    ys = np.random.RandomState(2).standard_normal((40, dy))
+    cov = A.T.astype(np.float64) @ A + sd * sd * np.eye(dy)
+    want = np.array([gaussian_logpdf(y, b.astype(np.float64), cov) for y in ys])
+    got = engine.cf_estimate(ys, sd, log=True)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    lin = engine.cf_estimate(ys, sd, log=False)
+    np.testing.assert_allclose(np.log(lin) - dy * np.log(sd), got, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 100003, 1000000])
+def test_mean_stderr_has_numpys_bits(engine, n):
+    rng = np.random.RandomState(n + 1)
+    v = rng.standard_normal(n) * rng.uniform(0.1, 50.0) - 300.0
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_mean = np.mean(v)
+            want_se = np.std(v) / np.sqrt(len(v)) if n else np.float64("nan")
+    mean, se = engine.mean_stderr(v)
+    if n == 0:
+        assert np.isnan(mean) and np.isnan(se)
+        return
+    assert mean == want_mean and se == want_se, (mean, want_mean, se, want_se)
+    # device-resident variant
+    v_d = engine.to_device(v)
+    o_d = engine.dev_alloc(16)
+    engine.mean_stderr_dev(v_d, n, o_d)
+    engine.sync()
+    got = engine.from_device(o_d, (2,), np.float64)
+    engine.dev_free(v_d)
+    engine.dev_free(o_d)
+    assert got[0] == want_mean and got[1] == want_se
+
+
+def test_is_estimate_summary(engine, make_nets):
+    gw, gb, hw, hb = make_nets(3, 6)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    y = np.random.RandomState(5).standard_normal((300, 6)) * 0.3
+    xhat = engine.mlp_forward(H, y.astype(np.float32))
+    est, mean, se = engine.is_estimate_summary(y, xhat, 500, 0.1, 0.1, df=1.0, seed=3, y_index_base=11)
+    assert np.array_equal(est, engine.is_estimate(y, xhat, 500, 0.1, 0.1, df=1.0, seed=3, log=True, y_index_base=11))
+    assert mean == np.mean(est) and se == np.std(est) / np.sqrt(len(est))
