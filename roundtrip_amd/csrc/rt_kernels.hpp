@@ -576,6 +576,25 @@ __global__ __launch_bounds__(64) void cf_finish_kernel(const double* y, const fl
 // (v - *mean_p)^2.  np_reduce_kernel (one thread) adds the buffers' sums in order and finishes the statistic.
 // ----------------------------------------------------------------------------------------------
 constexpr int NP_BUF = 8192;     // numpy's default ufunc buffer size, in elements
+// Separately rounded float64 operations.  hipcc contracts a * b + c into an fma by default (-ffp-contract=fast-honor-pragmas),
+// and HIP's __dadd_rn / __dmul_rn are plain operators in a header compiled that way, so they fuse too once inlined; the
+// operators below are compiled with contraction off.
+__device__ __forceinline__ double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double sub_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double div_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
 template <bool SQDEV>
 __global__ __launch_bounds__(256) void np_chunk_sum_kernel(const double* v, int64_t N, const double* mean_p,
                                                            double* chunk_sums) {
@@ -596,14 +615,14 @@ __global__ __launch_bounds__(256) void np_chunk_sum_kernel(const double* v, int6
     auto at = [&](int k) {
         const double x = v[lo + off + k];
         if (!SQDEV) return x;
-        const double t = __dsub_rn(x, mean);
-        return __dmul_rn(t, t);
+        const double t = sub_rn(x, mean);
+        return mul_rn(t, t);
     };
     if (real && len <= 128) {
         double res;
         if (len < 8) {
             res = 0.0;
-            for (int k = 0; k < len; ++k) res = __dadd_rn(res, at(k));
+            for (int k = 0; k < len; ++k) res = add_rn(res, at(k));
         } else {
             double r[8];
 #pragma unroll
@@ -611,29 +630,52 @@ __global__ __launch_bounds__(256) void np_chunk_sum_kernel(const double* v, int6
             int k = 8;
             for (; k < len - (len % 8); k += 8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], at(k + j));
+                for (int j = 0; j < 8; ++j) r[j] = add_rn(r[j], at(k + j));
             }
-            res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
-                            __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-            for (; k < len; ++k) res = __dadd_rn(res, at(k));
+            res = add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])),
+                            add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
+            for (; k < len; ++k) res = add_rn(res, at(k));
         }
         val[h] = res;
     }
     __syncthreads();
     for (int dd = 6; dd >= 0; --dd) {
-        if (real && d == dd && len > 128) val[h] = __dadd_rn(val[2 * h + 1], val[2 * h + 2]);
+        if (real && d == dd && len > 128) val[h] = add_rn(val[2 * h + 1], val[2 * h + 2]);
         __syncthreads();
     }
     if (h == 0) chunk_sums[blockIdx.x] = val[0];
 }
+// Correctly rounded float64 square root (what numpy's np.sqrt returns on the host): the device's sqrt() is an approximation
+// sequence that can be an ulp off.  One Newton step on the exact residual e = x - s^2 (an fma), then s moves to its
+// neighbour while the root lies beyond the midpoint between them.  The midpoint test is exact: with u = sn - s (one ulp,
+// signed) x - (s + u/2)^2 = (e - s u) - u^2/4, and e - s u is a multiple of u^2, so its sign (0 counted as "not beyond"
+// going up, "beyond" going down) decides.  For x where s^2 would lose bits to underflow the plain result is kept.
+__device__ double sqrt_cr(double x) {
+#pragma clang fp contract(off)
+    double s = sqrt(x);
+    if (!(x > 1e-290) || !(x < 1e300)) return s;
+    s = s + fma(-s, s, x) / (2.0 * s);
+    for (int it = 0; it < 4; ++it) {
+        const double e = fma(-s, s, x);
+        if (e == 0.0) break;
+        const double sn = (e > 0.0) ? nextafter(s, INFINITY) : nextafter(s, 0.0);
+        const double u = sn - s;
+        const double d = e - s * u;                       // s * u is exact (u is a power of two)
+        const bool beyond = (e > 0.0) ? (d > 0.0) : (d <= 0.0);
+        if (!beyond) break;
+        s = sn;
+    }
+    return s;
+}
+
 // stage 0: out2[0] = mean.  stage 1 (chunk_sums of the squared deviations): out2[1] = sqrt(sum / N) / sqrt(N).
 __global__ void np_reduce_kernel(const double* chunk_sums, int64_t nchunks, int64_t N, int stage, double* out2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double res = 0.0;
-    for (int64_t c = 0; c < nchunks; ++c) res = __dadd_rn(res, chunk_sums[c]);
-    const double q = __ddiv_rn(res, (double)N);
+    for (int64_t c = 0; c < nchunks; ++c) res = add_rn(res, chunk_sums[c]);
+    const double q = div_rn(res, (double)N);
     if (stage == 0) out2[0] = q;
-    else out2[1] = __ddiv_rn(__dsqrt_rn(q), __dsqrt_rn((double)N));
+    else out2[1] = div_rn(sqrt_cr(q), sqrt_cr((double)N));
 }
 
 // float32 feed of a float64 array: what the reference does when it hands y_points to the TF placeholder (:247)
