@@ -14,7 +14,10 @@ the eight_octagon_gmm 100x100 evaluation grid on [-5,5]^2 (/root/reference/evalu
 S = 10000 (evaluate.py:225), sd_y = 0.1, scale = 0.5, log=False, G = [2, 512x10, 2], H = [2, 256x10, 2],
 Glorot-uniform weights from RandomState(1234).  With N GPUs the grid is tiled N times
 and sharded contiguously (weak scaling: 10000 query points per GPU).  --workload selects BASELINE.md §4's other rows
-(config 3: AReM 3/6, S = 40000; config 5: YearPredictionMSD 20/90, strong 262144 points / weak 131072 per GPU).
+(config 1: indep-gmm; config 2's second grid: involute; config 3: arem, casp, S = 40000; config 4: hepmass, bank, and
+--g-units W for its synthetic width sweep; config 5: YearPredictionMSD 20/90, strong 262144 points / weak 131072 per GPU).
+With N > 1 the line carries a "ranks" object (every rank's kernel and wall time per step, the all-gather alone, the
+slowest rank), and --balance-ranks re-cuts the ranks' blocks by the rates measured on a warm-up step.
 
 No torch: device buffers, the collective (RCCL) and the timing fences all go through librt_is.so's C ABI.
 
@@ -39,9 +42,18 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X: 256 CU x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
 
 # name -> (dx, dy, sd_y, scale, default S, log, query points per GPU (weak) or in total (strong), scaling, description)
+# (query points None: a 2-D evaluation grid, --grid points a side, over the rectangle in GRID_RANGES)
 WORKLOADS = {
     "grid": (2, 2, 0.1, 0.5, 10000, False, None, "weak",
              "eight_octagon_gmm 2D evaluation grid %(g)dx%(g)d on [-5,5]^2 per GPU (evaluate.py shape)"),
+    "involute": (2, 2, 0.4, 0.5, 10000, False, None, "weak",
+                 "involute 2D evaluation grid %(g)dx%(g)d on [-6,5]x[-5,5] per GPU (evaluate.py:153-154, 238-239; BASELINE config 2)"),
+    "indep-gmm": (2, 2, 0.05, 0.5, 40000, True, None, "weak",
+                  "indep_gmm 2D evaluation grid %(g)dx%(g)d on [-1.5,1.5]^2 per GPU, S = 40000 (BASELINE config 1)"),
+    "hepmass": (8, 21, 0.1, 0.1, 40000, True, 100000, "weak",
+                "UCI HEPMASS 8/21, y ~ N(0,I) RandomState(42), 100000 query points per GPU (evaluate.py:163-168; BASELINE config 4)"),
+    "bank": (8, 17, 0.1, 0.1, 40000, True, 100000, "weak",
+             "UCI BANK 8/17, y ~ N(0,I) RandomState(42), 100000 query points per GPU (evaluate.py:163-168; BASELINE config 4)"),
     "arem": (3, 6, 0.1, 0.1, 40000, True, 125000, "weak",
              "UCI AReM 3/6, y ~ N(0,I) RandomState(42), 1M query points over 8 GPUs = 125000 per GPU (BASELINE config 3)"),
     "casp": (5, 9, 0.1, 0.1, 40000, True, 125000, "weak",
@@ -51,20 +63,23 @@ WORKLOADS = {
     "ypmsd-strong": (20, 90, 0.5, 0.1, 40000, True, 262144, "strong",
                      "UCI YearPredictionMSD 20/90, y ~ N(0,I) RandomState(42), 262144 query points in total (BASELINE config 5)"),
 }
+GRID_RANGES = {"grid": (-5.0, 5.0, -5.0, 5.0), "involute": (-6.0, 5.0, -5.0, 5.0), "indep-gmm": (-1.5, 1.5, -1.5, 1.5)}
 
 
-def build_nets(dx, dy):
+def build_nets(dx, dy, g_units=512):
+    """G = [dx, g_units x 10, dy] (the reference's is always 512 wide, main_density_est.py:447; other widths are BASELINE
+    config 4's synthetic LDS-capacity sweep), H = [dy, 256 x 10, dx] (:448)."""
     from roundtrip_amd import Generator
     rng = np.random.RandomState(1234)
-    g = Generator(dx, dy, "g_net", nb_layers=10, nb_units=512, rng=rng)
+    g = Generator(dx, dy, "g_net", nb_layers=10, nb_units=g_units, rng=rng)
     h = Generator(dy, dx, "h_net", nb_layers=10, nb_units=256, rng=rng)
     return g, h
 
 
-def grid_points(n=100, lo=-5.0, hi=5.0):
+def grid_points(n=100, lo=-5.0, hi=5.0, lo2=None, hi2=None):
     # create_2d_grid_data, /root/reference/util.py:568-573
     g1 = np.linspace(lo, hi, n)
-    g2 = np.linspace(lo, hi, n)
+    g2 = np.linspace(lo if lo2 is None else lo2, hi if hi2 is None else hi2, n)
     v1, v2 = np.meshgrid(g1, g2)
     return np.vstack((v1.ravel(), v2.ravel())).T
 
@@ -124,7 +139,8 @@ def recorded_traffic(key):
         except (OSError, ValueError):
             continue
         k = d.get("bench_key", {})
-        if (k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy")) == key and "traffic_bytes_per_launch" in d:
+        if (k.get("workload", "grid"), k.get("grid"), k.get("sample_size"), k.get("dx"), k.get("dy"), k.get("g_units", 512)) == key \
+                and "traffic_bytes_per_launch" in d:
             best = (d["traffic_bytes_per_launch"], "PMC passes recorded in profiles/%s" % os.path.basename(f))
     return best
 
@@ -195,10 +211,12 @@ def launch_ranks(n):
     only relays: the ranks inherit stdout/stderr (rank 0 prints the JSON line), and the exit code is the first failure's.
     A rank that fails takes the others down (by their exact PIDs)."""
     port = _free_port()
+    comm_port = _free_port()            # roundtrip_amd.dist's own rendezvous (RCCL's id): a port of its own, not MASTER_PORT + k
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_COMM_RUN_ID="bench-%d" % os.getpid())
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_COMM_RUN_ID="bench-%d" % os.getpid(),
+                   RT_COMM_PORT=str(comm_port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     import signal
 
@@ -238,7 +256,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="grid", choices=sorted(WORKLOADS),
                     help="grid = BASELINE config 2 (the default, what the metric is quoted on at N = 1); the others are "
-                         "BASELINE.md §4 rows 3 and 5 at full size")
+                         "BASELINE.md §4's other rows at full size (involute: config 2's second grid; indep-gmm: 1; arem, "
+                         "casp: 3; hepmass, bank: 4; ypmsd-*: 5)")
+    ap.add_argument("--g-units", type=int, default=512,
+                    help="hidden width of G (10 layers): BASELINE config 4's synthetic width sweep {64,128,256,512,1024}; the "
+                         "reference's G is always 512 wide")
+    ap.add_argument("--balance-ranks", action="store_true",
+                    help="N > 1: after the warm-up steps, re-cut the ranks' blocks of query points in proportion to the rate "
+                         "each rank measured on them (same results: a point's estimate depends on its global index only)")
     ap.add_argument("--sample-size", type=int, default=None, help="S (default: the workload's)")
     ap.add_argument("--grid", type=int, default=100, help="grid workload: grid side; query points per GPU = grid^2")
     ap.add_argument("--points", type=int, default=None,
@@ -284,24 +309,28 @@ def main():
 
     dx, dy, sd, scale, S_default, log, n_points, scaling, desc = WORKLOADS[args.workload]
     S = args.sample_size or S_default
-    g, h = build_nets(dx, dy)
+    g, h = build_nets(dx, dy, args.g_units)
     eng = _lib.Engine(dev_index)
     eng.set_mlp(_lib.RT_MLP_G, g.weights, g.biases, g.alpha)
     eng.set_mlp(_lib.RT_MLP_H, h.weights, h.biases, h.alpha)
     if world > 1 and not use_gloo:
         rdist.init(eng)                            # RCCL communicator on the engine's device and stream
 
-    if args.workload == "grid":
+    is_grid = n_points is None
+    if is_grid:
         per_gpu = args.grid * args.grid
         n_total = per_gpu * world
-        tile = grid_points(args.grid)
-        lo, hi = rdist.shard_bounds(n_total, world, rank)
-        y_mine = np.ascontiguousarray(np.tile(tile, (world, 1))[lo:hi])
+        tile = grid_points(args.grid, *GRID_RANGES[args.workload])
         desc = desc % {"g": args.grid}
     else:
         n_points = args.points or n_points
         n_total = n_points * world if scaling == "weak" else n_points
-        lo, hi = rdist.shard_bounds(n_total, world, rank)
+
+    def rows(lo, hi):
+        """Query points [lo, hi) of the job's one global list (the same whatever the rank count or the cut)."""
+        if is_grid:       # the grid, tiled once per GPU
+            idx = np.arange(lo, hi) % per_gpu
+            return np.ascontiguousarray(tile[idx])
         # rows [lo, hi) of the one global stream RandomState(42).standard_normal((n_total, dy)), float32 values
         rs = np.random.RandomState(42)
         skip = lo * dy
@@ -309,27 +338,51 @@ def main():
             k = min(skip, 1 << 24)
             rs.standard_normal(k)
             skip -= k
-        y_mine = rs.standard_normal((hi - lo, dy)).astype(np.float32).astype(np.float64)
-    per = -(-n_total // world)
-    n_mine = hi - lo
-    y_dev = eng.to_device(y_mine)                                              # float64, resident
-    y32_dev = eng.to_device(y_mine.astype(np.float32))                         # H's float32 feed
-    xhat_dev = eng.dev_alloc(max(1, n_mine) * dx * 4)
-    out_dev = eng.to_device(np.zeros(per, dtype=np.float64))
-    gathered_dev = eng.dev_alloc(per * world * 8) if world > 1 and not use_gloo else None
+        return rs.standard_normal((hi - lo, dy)).astype(np.float32).astype(np.float64)
+
+    # device buffers of this rank's block (re-made when --balance-ranks re-cuts the blocks after the warm-up)
+    bufs = {}
+
+    def place(bounds):
+        """Uploads this rank's block under `bounds` (one (lo, hi) per rank): y (float64 + H's float32 feed), xhat, out;
+        `per` = the largest block, which every rank contributes to the all-gather (padded)."""
+        for k in ("y", "y32", "xhat", "out", "gathered"):
+            if bufs.get(k):
+                eng.dev_free(bufs[k])
+        lo, hi = bounds[rank]
+        per = max(1, max(b[1] - b[0] for b in bounds))
+        y_mine = rows(lo, hi)
+        bufs.update(lo=lo, hi=hi, n=hi - lo, per=per, bounds=bounds, y_host=y_mine,
+                    y=eng.to_device(y_mine), y32=eng.to_device(y_mine.astype(np.float32)),
+                    xhat=eng.dev_alloc(max(1, hi - lo) * dx * 4), out=eng.to_device(np.zeros(per, dtype=np.float64)),
+                    gathered=eng.dev_alloc(per * world * 8) if world > 1 and not use_gloo else None)
+
+    place([rdist.shard_bounds(n_total, world, r) for r in range(world)])
     gathered_host = None
 
-    def step():
+    def step(gather=True):
         nonlocal gathered_host
-        eng.mlp_forward_dev(_lib.RT_MLP_H, y32_dev, n_mine, xhat_dev)
-        eng.is_estimate_dev(y_dev, xhat_dev, n_mine, S, sd, scale, out_dev, df=1.0, seed=0, log=log, y_index_base=lo)
-        if world > 1:
+        b = bufs
+        eng.mlp_forward_dev(_lib.RT_MLP_H, b["y32"], b["n"], b["xhat"])
+        eng.is_estimate_dev(b["y"], b["xhat"], b["n"], S, sd, scale, b["out"], df=1.0, seed=0, log=log, y_index_base=b["lo"])
+        if world > 1 and gather:
             if use_gloo:
-                loc = torch.from_numpy(eng.from_device(out_dev, (per,), np.float64))       # waits for the stream
-                gathered_host = torch.empty(per * world, dtype=torch.float64)
+                loc = torch.from_numpy(eng.from_device(b["out"], (b["per"],), np.float64))       # waits for the stream
+                gathered_host = torch.empty(b["per"] * world, dtype=torch.float64)
                 tdist.all_gather_into_tensor(gathered_host, loc)
             else:
-                eng.comm_all_gather_dev(out_dev, per, gathered_dev)                        # same stream, no host hop
+                eng.comm_all_gather_dev(b["out"], b["per"], b["gathered"])                   # same stream, no host hop
+
+    def gather_doubles(vals):
+        """(world, len(vals)) float64: every rank's `vals` (the bookkeeping of the N > 1 line, not the data path)."""
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        if world == 1:
+            return v[None, :]
+        if use_gloo:
+            out = torch.empty(world * v.size, dtype=torch.float64)
+            tdist.all_gather_into_tensor(out, torch.from_numpy(v))
+            return out.numpy().reshape(world, v.size)
+        return eng.comm_all_gather(v)
 
     def barrier():
         if world > 1:
@@ -359,40 +412,85 @@ def main():
     # not a warm-up step: one tiny H forward, so that loading the library's code object (all kernels are in one; by the
     # metric's definition library load is outside the measured call) never lands in a timed step, even under --warmup 0.
     # No extra launch of the fused kernel: the rocprofv3 --stats average of this command is over equal launches.
-    if n_mine > 0:
-        eng.mlp_forward_dev(_lib.RT_MLP_H, y32_dev, min(n_mine, 64), xhat_dev)
+    if bufs["n"] > 0:
+        eng.mlp_forward_dev(_lib.RT_MLP_H, bufs["y32"], min(bufs["n"], 64), bufs["xhat"])
         eng.sync()
     for _ in range(args.warmup):
         step()
     eng.sync()          # everything this process puts on the GPU runs on the engine's stream
+    rank_weights = None
+    if world > 1 and args.balance_ranks:
+        # one more untimed step, measured: every rank's rate on ITS block (query points per ms of its fused kernel); the
+        # blocks are then re-cut in proportion.  Ranks that would change by less than 0.2 % keep the equal cut.
+        barrier()
+        eng.reset_counters()
+        step(gather=False)
+        eng.sync()
+        rate = bufs["n"] / max(1e-9, eng.counters()["kernel_ms"])
+        rates = gather_doubles([rate])[:, 0]
+        if rates.min() > 0 and rates.max() / rates.min() > 1.002:
+            rank_weights = [float(v) for v in rates]
+            place([rdist.shard_bounds(n_total, world, r, rank_weights) for r in range(world)])
+            step(gather=False)                                # buffers touched once before the timed region
+            eng.sync()
     barrier()
     eng.reset_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     eng.sync()
-    elapsed = time.perf_counter() - t0
+    local_elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = max_over_ranks(elapsed)
+    elapsed = max_over_ranks(local_elapsed)
     ctr = eng.counters()
+    attribution = None
+    if world > 1:
+        # what a scaling loss would be made of: every rank's kernel time and wall time per step, and the all-gather alone
+        # (5 stand-alone gathers of the same payload after the timed region, between barriers)
+        t_g = []
+        for _ in range(5):
+            barrier()
+            tg0 = time.perf_counter()
+            if use_gloo:
+                loc = torch.zeros(bufs["per"], dtype=torch.float64)
+                tdist.all_gather_into_tensor(torch.empty(bufs["per"] * world, dtype=torch.float64), loc)
+            else:
+                eng.comm_all_gather_dev(bufs["out"], bufs["per"], bufs["gathered"])
+                eng.sync()
+            t_g.append((time.perf_counter() - tg0) * 1e3)
+        mine = [ctr["kernel_ms"] / args.steps, local_elapsed / args.steps * 1e3, float(np.median(t_g)), float(bufs["n"])]
+        allr = gather_doubles(mine)
+        k_ms = allr[:, 0]
+        attribution = {
+            "per_rank_kernel_ms": [round(float(v), 3) for v in k_ms],
+            "per_rank_step_ms": [round(float(v), 3) for v in allr[:, 1]],
+            "per_rank_query_points": [int(v) for v in allr[:, 3]],
+            "slowest_rank": int(np.argmax(k_ms)),
+            "gather_ms": round(float(allr[:, 2].max()), 3),
+            "efficiency_vs_slowest": float(k_ms.mean() / k_ms.max()) if k_ms.max() > 0 else None,
+            "non_kernel_ms": round(float(elapsed / args.steps * 1e3 - k_ms.max()), 3),
+            "rank_weights": rank_weights,
+            "note": "kernel = the fused IS kernel's launches (HIP events on each rank's stream); step = the rank's own wall "
+                    "time per step; gather_ms = the all-gather alone (median of 5, max over ranks); efficiency_vs_slowest = "
+                    "mean / max of the ranks' kernel times (1 = balanced); non_kernel_ms = job ms_per_step - slowest kernel",
+        }
 
     if rank == 0:
         evals = float(n_total) * S * args.steps
+        per, bounds = bufs["per"], bufs["bounds"]
         if world == 1:
-            res = eng.from_device(out_dev, (per,), np.float64)[:n_total]
-        elif use_gloo:
-            res = gathered_host.numpy()[:n_total]
+            res = eng.from_device(bufs["out"], (per,), np.float64)[:n_total]
         else:
-            res = eng.from_device(gathered_dev, (per * world,), np.float64)[:n_total]
+            flat = gathered_host.numpy() if use_gloo else eng.from_device(bufs["gathered"], (per * world,), np.float64)
+            res = np.concatenate([flat[r * per: r * per + (b[1] - b[0])] for r, b in enumerate(bounds)])
         achieved = ctr["flops"] / (ctr["kernel_ms"] * 1e-3) / 1e12 if ctr["kernel_ms"] > 0 else 0.0
         traffic = None
-        child_args = ["--workload", args.workload, "--grid", str(args.grid), "--sample-size", str(S)] + \
-            (["--points", str(args.points)] if args.points else [])
+        child_args = ["--workload", args.workload, "--grid", str(args.grid), "--sample-size", str(S), "--g-units",
+                      str(args.g_units)] + (["--points", str(args.points)] if args.points else [])
         if world == 1 and not args.no_live_traffic:
             traffic = live_traffic(child_args)
-        if traffic is None and args.workload == "grid":
-            traffic = recorded_traffic((args.grid, S, dx, dy))
-        share = dx + 1 > 4
+        if traffic is None:
+            traffic = recorded_traffic((args.workload, args.grid if is_grid else None, S, dx, dy, args.g_units))
         line = {
             "metric": "IS sample-evals/sec (N_y x S through G)",
             "value": evals / elapsed,
@@ -406,23 +504,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s, dx=%d dy=%d, S=%d, sd_y=%g scale=%g df=1 log=%s, G=[%d,512x10,%d] H=[%d,256x10,%d] "
-                                   "Glorot RandomState(1234)" % (desc, dx, dy, S, sd, scale, log, dx, dy, dy, dx),
+            "config": {"workload": "%s, dx=%d dy=%d, S=%d, sd_y=%g scale=%g df=1 log=%s, G=[%d,%dx10,%d] H=[%d,256x10,%d] "
+                                   "Glorot RandomState(1234)" % (desc, dx, dy, S, sd, scale, log, dx, args.g_units, dy, dy, dx),
                        "query_points_total": int(n_total), "sample_size": S, "parallelism": "y-shard x%d" % world,
                        "collective": None if world == 1 else ("gloo (rehearsal)" if use_gloo else "rccl all-gather")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic[0] if traffic else None, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "is_fused_kernel<512, 2, false, %s, 4>" % ("true" if share else "false"),
+                         "kernel": eng.is_kernel_name(1.0),
                          "kernel_ms_avg": ctr["kernel_ms"] / max(1, ctr["launches"]),
                          "launches": ctr["launches"],
                          "flops_per_sample_eval": ctr["flops"] / max(1, ctr["sample_evals"])},
             "result_check": {"finite": bool(np.all(np.isfinite(res))), "mean": float(res.mean())},
         }
+        if attribution is not None:
+            line["ranks"] = attribution
+            line["roofline"]["note"] = "rank 0's kernel; every rank's kernel time is in ranks.per_rank_kernel_ms"
         if world == 1 and not args.no_cpu_baseline:
-            y_host = y_mine
-            line["cpu_baseline"] = cpu_baseline(g, h, y_host, S, sd, scale, log, args.cpu_points, args.cpu_points_numpy, eng)
+            line["cpu_baseline"] = cpu_baseline(g, h, bufs["y_host"], S, sd, scale, log, args.cpu_points,
+                                                args.cpu_points_numpy, eng)
         print(json.dumps(line), flush=True)
     done.set()
     barrier()
@@ -430,8 +531,8 @@ def main():
         rdist.shutdown()
     if tdist is not None:
         tdist.destroy_process_group()
-    for p in (y_dev, y32_dev, xhat_dev, out_dev, gathered_dev):
-        eng.dev_free(p)
+    for k in ("y", "y32", "xhat", "out", "gathered"):
+        eng.dev_free(bufs[k])
     eng.close()
 
 

@@ -247,6 +247,11 @@ int rt_sync(rt_ctx* ctx);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out);
 int rt_reset_counters(rt_ctx* ctx);
 
+/* The instantiation of the fused kernel rt_is_estimate launches for the G that is set and this df (hidden width the net
+ * is padded to, sample tiles per wave, given-samples flag, shared-sampler flag, waves per workgroup), e.g.
+ * "is_fused_kernel<512, 2, false, false, 4>": the name a rocprofv3 kernel trace shows, for reports (bench.py). */
+int rt_is_kernel_name(rt_ctx* ctx, double df, char* buf, size_t cap);
+
 /* Device facts the host side needs for work partitioning. */
 int rt_device_cu_count(rt_ctx* ctx, int* out);
 

@@ -24,7 +24,7 @@ SYMBOLS = (
     "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_dev_mem_info",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
     "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
-    "rt_cf_estimate", "rt_cf_estimate_dev", "rt_mean_stderr", "rt_mean_stderr_dev", "rt_is_estimate_summary",
+    "rt_is_kernel_name", "rt_cf_estimate", "rt_cf_estimate_dev", "rt_mean_stderr", "rt_mean_stderr_dev", "rt_is_estimate_summary",
 )
 
 RT_ETOOBIG = 6
@@ -99,6 +99,7 @@ def load():
     lib.rt_comm_all_gather_f64_dev.argtypes = [vp, vp, i64, vp]
     lib.rt_comm_all_reduce_max_f64.argtypes = [vp, vp, i64]
     lib.rt_comm_barrier.argtypes = [vp]
+    lib.rt_is_kernel_name.argtypes = [vp, dbl, C.c_char_p, C.c_size_t]
     lib.rt_cf_estimate.argtypes = [vp, vp, i64, dbl, C.c_int, vp]
     lib.rt_cf_estimate_dev.argtypes = [vp, vp, i64, dbl, C.c_int, vp]
     lib.rt_mean_stderr.argtypes = [vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl)]
@@ -413,6 +414,12 @@ class Engine(object):
         a = (C.c_double * 8)()
         self._chk(self._lib.rt_get_xcd_shares(self._h, a))
         return np.array(list(a))
+
+    def is_kernel_name(self, df=1.0):
+        """The fused kernel's instantiation for the G that is set, as a kernel trace names it."""
+        buf = C.create_string_buffer(128)
+        self._chk(self._lib.rt_is_kernel_name(self._h, float(df), buf, 128))
+        return buf.value.decode()
 
     def cu_count(self):
         n = C.c_int()

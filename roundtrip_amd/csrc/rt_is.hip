@@ -1009,6 +1009,18 @@ int rt_is_estimate_dev_noalloc(rt_ctx* ctx, const double* y_dev, const float* xh
     return rc;
 }
 
+int rt_is_kernel_name(rt_ctx* ctx, double df, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return RT_EINVAL;
+    HostMlp& G = ctx->mlp[RT_MLP_G];
+    if (!G.set) return fail(ctx, RT_ENOTSET, "G (RT_MLP_G) has not been set");
+    SamplerArgs sa;
+    const int rc = make_sampler(ctx, 1.0, df, 0, sa);
+    if (rc) return rc;
+    const bool share = G.nw > 1 && sa.ndf + G.args.in_dim > 4;      // launch_is's choice
+    snprintf(buf, cap, "is_fused_kernel<%d, %d, false, %s, %d>", G.hid, G.nst, share ? "true" : "false", G.nw);
+    return RT_OK;
+}
+
 int rt_is_pair_count(rt_ctx* ctx, int64_t S, int64_t* E) {
     if (!ctx || !E) return RT_EINVAL;
     HostMlp& G = ctx->mlp[RT_MLP_G];

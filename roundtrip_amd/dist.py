@@ -25,15 +25,49 @@ _MAGIC_ERR = b"RTER"     # rank 0 could not make the id: 128 bytes of its error 
 _PORT_SPAN = 16          # candidate rendezvous ports: MASTER_PORT + 1 .. MASTER_PORT + _PORT_SPAN
 _native = None           # (engine, rank, world_size) once init() has run
 _epoch = 0               # rendezvous count of this process: keeps a second init() from meeting a stale first one
+_weights = None          # per-rank shares of the query points (set_rank_weights); None: equal blocks
 
 
-def shard_bounds(n, world_size, rank):
-    """Contiguous block [lo, hi) of rank `rank`: ceil(n / world_size) points per rank, last ranks may be short
-    or empty."""
-    per = -(-int(n) // int(world_size)) if n > 0 else 0
+def shard_bounds(n, world_size, rank, weights=None):
+    """Contiguous block [lo, hi) of rank `rank`.  Equal shares (the default): ceil(n / world_size) points per rank, last
+    ranks may be short or empty.  `weights` (one positive number per rank, the same on every rank): block r gets
+    round(n * w_r / sum(w)) of the points, cut at the rounded cumulative shares — for ranks of unequal speed."""
+    n, world_size = int(n), int(world_size)
+    if weights is not None:
+        w = [float(v) for v in weights]
+        if len(w) != world_size or min(w) <= 0.0:
+            raise ValueError("need one positive weight per rank")
+        tot = sum(w)
+        cut = [0]
+        acc = 0.0
+        for v in w[:-1]:
+            acc += v
+            cut.append(min(n, max(cut[-1], int(n * (acc / tot) + 0.5))))
+        cut.append(n)
+        return cut[rank], cut[rank + 1]
+    per = -(-n // world_size) if n > 0 else 0
     lo = min(n, rank * per)
     hi = min(n, lo + per)
     return lo, hi
+
+
+def set_rank_weights(weights):
+    """Switch from equal blocks to blocks proportional to `weights` (one per rank, identical on every rank; None: back to
+    equal blocks) in sharded_map / all_gather_blocks.  The GPUs of a node do not run at one clock (the eight XCDs of ONE
+    chip are 1-2 % apart); a caller that has measured its ranks' rates — bench.py --balance-ranks does, on a
+    warm-up step — hands them over here.  Results cannot change: a query point's estimate depends on its GLOBAL index,
+    not on the rank that evaluates it."""
+    global _weights
+    if weights is not None:
+        weights = [float(v) for v in weights]
+        if min(weights) <= 0.0:
+            raise ValueError("weights must be positive")
+    _weights = weights
+
+
+def rank_weights():
+    rank, ws = world()
+    return _weights if _weights is not None and len(_weights) == ws else None
 
 
 # ---- rendezvous: rank 0 hands RCCL's unique id to the other ranks ------------------------------------------------
@@ -61,7 +95,11 @@ def exchange_id(make_id, rank, world_size, addr, port, timeout=300.0, epoch=0):
         return make_id()
     tok = _token(addr, port, world_size, epoch)
     deadline = time.time() + timeout
-    cands = [port + 1 + i for i in range(_PORT_SPAN)]
+    # RT_COMM_PORT (set for all ranks by whoever starts them; bench.py --gpus N does): exactly that port.  Otherwise the
+    # first free one of MASTER_PORT + 1 .. + 16 — which can collide with a neighbouring job's MASTER_PORT when jobs on one
+    # node use consecutive ones: give such jobs RT_COMM_PORT, or MASTER_PORTs further apart.
+    fixed = os.environ.get("RT_COMM_PORT")
+    cands = [int(fixed)] if fixed else [port + 1 + i for i in range(_PORT_SPAN)]
     if rank == 0:
         srv = None
         for p in cands:
@@ -214,15 +252,26 @@ def all_gather_blocks(local, n, device=None):
 
     One all-gather of ceil(n / world) float64 per rank — the only collective on the path.  Payloads are tiny
     (1M points = 8 MB in total), so this is latency- not bandwidth-bound; a single direct all-gather is right.
+    With rank weights set (set_rank_weights) the blocks are unequal: every rank sends the LARGEST block's length, padded,
+    and the blocks are cut out of the gathered rows by their bounds.
     `device` only matters for a caller-owned torch "nccl" group (the HIP device index of the engine)."""
     rank, ws = world()
     if not active():
         return np.asarray(local, dtype=np.float64)
-    per = -(-int(n) // ws)
-    buf = np.zeros(per, dtype=np.float64)
+    n = int(n)
+    w = rank_weights()
     loc = np.asarray(local, dtype=np.float64).reshape(-1)
+    if w is None:
+        per = -(-n // ws)
+        buf = np.zeros(per, dtype=np.float64)
+        buf[: loc.size] = loc
+        return _gather_rows(buf, device).reshape(-1)[:n].copy()
+    bounds = [shard_bounds(n, ws, r, w) for r in range(ws)]
+    per = max(1, max(hi - lo for lo, hi in bounds))
+    buf = np.zeros(per, dtype=np.float64)
     buf[: loc.size] = loc
-    return _gather_rows(buf, device).reshape(-1)[:n].copy()
+    rows = _gather_rows(buf, device)
+    return np.concatenate([rows[r, : hi - lo] for r, (lo, hi) in enumerate(bounds)])
 
 
 def sharded_map(points, fn, device=None):
@@ -232,7 +281,7 @@ def sharded_map(points, fn, device=None):
     points = np.asarray(points)
     n = points.shape[0]
     rank, ws = world()
-    lo, hi = shard_bounds(n, ws, rank)
+    lo, hi = shard_bounds(n, ws, rank, rank_weights())
     local = fn(points[lo:hi], lo) if hi > lo else np.zeros(0, dtype=np.float64)
     return all_gather_blocks(local, n, device)
 

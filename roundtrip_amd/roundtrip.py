@@ -193,7 +193,7 @@ class _IsModelBase(object):
         if not (self.shard and dist.active()):
             centres = eng.mlp_forward(_lib.RT_MLP_H, points.astype(np.float32))
             return eng.is_estimate_multi(points, centres, sample_size, sds, scale, df=df, seed=self.is_seed, log=log)
-        lo, hi = dist.shard_bounds(points.shape[0], ws, rank)
+        lo, hi = dist.shard_bounds(points.shape[0], ws, rank, dist.rank_weights())
         local = np.zeros((len(sds), 0))
         if hi > lo:
             centres = eng.mlp_forward(_lib.RT_MLP_H, points[lo:hi].astype(np.float32))

@@ -587,6 +587,103 @@ def test_sharded_map_world_size_2_gloo(tmp_path, n):
     assert res.stdout.count("rank ok") == 2
 
 
+def test_weighted_shard_bounds_partition_the_points():
+    """shard_bounds with rank weights: contiguous, disjoint, covering, monotone in the weights; equal weights land within
+    one point of the equal cut; bad weights are refused."""
+    from roundtrip_amd import dist as rdist
+    rng = np.random.RandomState(0)
+    for n in (0, 1, 2, 7, 100, 1000003):
+        for ws in (1, 2, 3, 8):
+            w = rng.uniform(0.5, 2.0, ws)
+            cuts = [rdist.shard_bounds(n, ws, r, w) for r in range(ws)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(ws - 1)) and all(lo <= hi for lo, hi in cuts)
+            for r, (lo, hi) in enumerate(cuts):
+                assert abs((hi - lo) - n * w[r] / w.sum()) <= 1.0 + 1e-9
+            eq = [rdist.shard_bounds(n, ws, r, [1.0] * ws) for r in range(ws)]
+            assert all(abs((hi - lo) - n / ws) <= 1.0 for lo, hi in eq)
+    with pytest.raises(ValueError):
+        rdist.shard_bounds(10, 2, 0, [1.0])
+    with pytest.raises(ValueError):
+        rdist.shard_bounds(10, 2, 0, [1.0, 0.0])
+
+
+@pytest.mark.parametrize("n", [11, 3, 1])
+def test_weighted_sharded_map_world_size_2_gloo(tmp_path, n):
+    """Ranks of unequal speed (set_rank_weights): the blocks are cut 3 : 1, every rank contributes the LARGEST block's
+    length to the all-gather (padded) and the result is the unsharded answer, bit for bit; back to equal blocks
+    afterwards."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import torch.distributed as dist
+        from roundtrip_amd import dist as rdist
+        dist.init_process_group("gloo")
+        n = %d
+        pts = np.arange(n * 3, dtype=np.float64).reshape(n, 3)
+        want = pts.sum(axis=1) * 1000.0 + np.arange(n)
+        for weights in ([3.0, 1.0], [1.0, 3.0], None):
+            rdist.set_rank_weights(weights)
+            calls = []
+            def fn(block, base):
+                calls.append((base, len(block)))
+                return block.sum(axis=1) * 1000.0 + base + np.arange(len(block))      # depends on the GLOBAL index
+            out = rdist.sharded_map(pts, fn)
+            lo, hi = rdist.shard_bounds(n, 2, dist.get_rank(), weights)
+            assert calls == ([(lo, hi - lo)] if hi > lo else []), (weights, calls)
+            assert out.dtype == np.float64 and np.array_equal(out, want), (weights, out, want)
+        if n == 11:
+            assert rdist.shard_bounds(n, 2, 0, [3.0, 1.0]) == (0, 8) and rdist.shard_bounds(n, 2, 1, [3.0, 1.0]) == (8, 11)
+        dist.barrier(); dist.destroy_process_group()
+        print("rank ok")
+    """ % (ROOT, n)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("rank ok") == 2
+
+
+def test_rendezvous_on_a_port_of_its_own(tmp_path):
+    """RT_COMM_PORT: the id exchange uses exactly that port (bench.py --gpus N picks a free one for its ranks), not
+    MASTER_PORT + 1 .. + 16 — which a neighbouring job's MASTER_PORT may be."""
+    port, comm_port = _free_port(), _free_port()
+    script = tmp_path / "r.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        from roundtrip_amd import dist as rdist
+        rank, ws, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        uid = rdist.exchange_id(lambda: bytes([(3 * i + rank) %% 256 for i in range(128)]), rank, ws, "127.0.0.1", port,
+                                timeout=60.0)
+        assert uid == bytes([(3 * i) %% 256 for i in range(128)])
+        print("rank ok")
+    """ % (ROOT,)))
+    # the whole MASTER_PORT + 1 .. + 16 window is occupied by foreign listeners: only RT_COMM_PORT can work
+    blockers = []
+    for k in range(1, 17):
+        b = socket.socket()
+        try:
+            b.bind(("127.0.0.1", port + k))
+            b.listen(1)
+            blockers.append(b)
+        except OSError:
+            b.close()
+    try:
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, env=dict(os.environ, RT_COMM_PORT=str(comm_port)))
+                 for r in range(2)]
+        outs = [p.communicate(timeout=120) for p in procs]
+    finally:
+        for b in blockers:
+            b.close()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "rank ok" in so, so + se
+
+
 def test_all_gather_ranges_world_size_2_gloo(tmp_path):
     """The second sharding axis on CPU: two gloo ranks each hold their range of a query point's pairs (axis 1); the
     gather returns the whole array on both — for a total that divides evenly, one that does not, and one smaller than

@@ -427,6 +427,15 @@ def test_two_ranks_through_rt_comm(tmp_path):
             assert got[k].shape == one[k].shape and np.array_equal(got[k], one[k]), (k, got[k], one[k])
         for S in (900, 650):                                         # fewer points than ranks: samples split
             assert np.array_equal(m.estimate_py_with_IS(y[:1], 0, sd_y=0.1, scale=0.1, sample_size=S, save=False), alone[S])
+        # ranks of unequal speed: blocks cut 3 : 1 (10 + 3 points) and 1 : 3, a padded all-gather — the same bits
+        for w in ([3.0, 1.0], [1.0, 3.0]):
+            rdist.set_rank_weights(w)
+            lo, hi = rdist.shard_bounds(13, 2, rank, rdist.rank_weights())
+            assert (hi - lo) == ((10, 3) if w[0] > w[1] else (3, 10))[rank]
+            got = run()
+            for k in got:
+                assert got[k].shape == one[k].shape and np.array_equal(got[k], one[k]), (w, k)
+        rdist.set_rank_weights(None)
         m.split_samples = True
         assert np.array_equal(m.estimate_py_with_IS(y, 0, sd_y=0.1, scale=0.1, sample_size=900, save=False), one["IS"])
         rdist.shutdown()
@@ -484,6 +493,23 @@ def test_bench_two_ranks_default_backend(tmp_path):
     assert len(lines) == 1
     d2 = json.loads(lines[0])
     assert d2["n_gpus"] == 2 and d2["result_check"] == d["result_check"] and d2["config"] == d["config"]
+    # the N > 1 line explains itself: every rank's kernel and wall time per step, the gather alone, the slowest rank
+    for line in (d, d2):
+        r = line["ranks"]
+        assert len(r["per_rank_kernel_ms"]) == 2 and len(r["per_rank_step_ms"]) == 2 and r["per_rank_query_points"] == [256, 256]
+        assert min(r["per_rank_kernel_ms"]) > 0 and r["slowest_rank"] in (0, 1) and r["gather_ms"] > 0
+        assert 0.5 <= r["efficiency_vs_slowest"] <= 1.0 and r["rank_weights"] is None
+        assert line["roofline"]["kernel"] == "is_fused_kernel<512, 2, false, false, 4>"
+    # --balance-ranks: blocks re-cut by the rates measured on a warm-up step (two ranks contending for ONE GPU here, so the
+    # rates are whatever they are); the gathered result does not change by a bit
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1",
+                          "--warmup", "1", "--grid", "16", "--sample-size", "640", "--balance-ranks"],
+                         env=dict(env, RT_RCCL_LIB=_COMM_DOUBLE), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d3 = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d3["result_check"] == d["result_check"] and sum(d3["ranks"]["per_rank_query_points"]) == 512
+    if d3["ranks"]["rank_weights"] is not None:
+        assert len(d3["ranks"]["rank_weights"]) == 2
     # the same 512 global points (the 16 x 16 tile twice, global indices 0..511) evaluated by one process
     import numpy as np
     sys.path.insert(0, root)
@@ -499,3 +525,28 @@ def test_bench_two_ranks_default_backend(tmp_path):
     want = eng.is_estimate(y, xhat, 640, sd, scale, df=1.0, seed=0, log=log)
     eng.close()
     assert d["result_check"]["mean"] == float(want.mean())
+
+
+@pytest.mark.parametrize("args", [["--workload", "hepmass"], ["--workload", "bank"], ["--workload", "arem"],
+                                  ["--workload", "involute", "--grid", "16"], ["--workload", "indep-gmm", "--grid", "16"],
+                                  ["--workload", "hepmass", "--g-units", "64"], ["--workload", "hepmass", "--g-units", "128"],
+                                  ["--workload", "hepmass", "--g-units", "256"], ["--workload", "hepmass", "--g-units", "1024"]])
+def test_bench_workloads_smoke(args):
+    """Every BASELINE row bench.py can run (--workload, --g-units) at 256 query points: one JSON line with the roofline
+    (kernel name from the library) and the CPU legs, which agree with the GPU on their sample."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--points", "256",
+                          "--sample-size", "640", "--no-live-traffic", "--cpu-points", "8", "--cpu-points-numpy", "2"] + args,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["query_points_total"] == 256 and d["result_check"]["finite"]
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0 and d["roofline"]["launches"] == 1
+    width = int(args[args.index("--g-units") + 1]) if "--g-units" in args else 512
+    assert d["roofline"]["kernel"].startswith("is_fused_kernel<%d," % width)
+    assert "matches GPU on this sample: True" in d["cpu_baseline"]["sample"]
+    assert "matches GPU on this sample: True" in d["cpu_baseline"]["numpy_restatement"]["sample"]
