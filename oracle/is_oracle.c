@@ -365,7 +365,7 @@ int rto_is_estimate_given_samples(void* gp, const double* y, const float* xhat, 
 /* ---------------------------------------------------------------------------------------------
  * This repo's proposal sampler (rt_is.hip draw_sample), restated: Philox4x32-10 keyed by the seed,
  * counter (sample index, call index, y index lo, y index hi); call c yields normals g[4c..4c+3] by two
- * float32 Box-Muller transforms; chi2 = g[0]^2+..+g[ndf-1]^2 for integer df <= 32;
+ * float32 Box-Muller transforms (r = sqrt(-2 ln2 log2 u1), angle u2 revolutions); chi2 = g[0]^2+..+g[ndf-1]^2 for integer df <= 32;
  * x_d = xhat_d + scale*g[ndf+d]/sqrt(chi2/df); any other df: chi2_over_df_gamma below.  libm's logf/sincosf may differ from the GPU's in the
  * last ulp, so agreement with the GPU draws is to a few ulp, not bitwise.
  * --------------------------------------------------------------------------------------------- */
@@ -386,11 +386,13 @@ void rto_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) 
     for (int i = 0; i < 4; ++i) out[i] = c[i];
 }
 static float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); } /* (k+1/2)/2^23: exact, in (0,1) */
+/* rt_sampler.hpp box_muller: r = sqrt((-2 ln 2) log2 u1), the angle u2 in revolutions.  The GPU evaluates log2, sqrt, sin
+ * and cos on its transcendental unit; here the angle's sine and cosine are taken in double and rounded once. */
 static void box_muller(uint32_t a, uint32_t b, float* n0, float* n1) {
-    const float r = sqrtf(-2.0f * logf(u01(a)));
-    const float th = 6.28318530717958647692f * u01(b);
-    *n0 = r * cosf(th);
-    *n1 = r * sinf(th);
+    const float r = sqrtf(-1.38629436111989061883f * log2f(u01(a)));
+    const double th = 6.28318530717958647692 * (double)u01(b);
+    *n0 = r * (float)cos(th);
+    *n1 = r * (float)sin(th);
 }
 
 /* chi2(df)/df for a df that is not an integer in [1, 32] (rt_sampler.hpp chi2_over_df_gamma): chi2 = 2*Gamma(df/2, 1)
@@ -426,14 +428,15 @@ int rto_draw_samples(const float* xhat, int64_t N, int64_t y_index_base, int64_t
                      double df, uint64_t seed, float* xs) {
     if (!(df > 0.0)) return 1;
     const int ndf = (df == floor(df) && df <= 32.0) ? (int)df : 0;   /* 0: the gamma path */
-    const float fscale = (float)scale, fdf = (float)df;
+    const float fscale = (float)scale, fdf = (float)df, inv_df = (float)(1.0 / df);
     for (int64_t n = 0; n < N; ++n)
         for (int64_t i = 0; i < S; ++i) {
             const uint64_t yi = (uint64_t)(y_index_base + n);
             float zsum = 0.0f, mult = 0.0f;
+            /* mult = scale * rsq(max(chi2 / df, 1e-30)): the clamp of rt_sampler.hpp draw_sample */
             if (ndf == 0)
-                mult = fscale / sqrtf(chi2_over_df_gamma(fdf, (uint32_t)i, (uint32_t)yi, (uint32_t)(yi >> 32),
-                                                         (uint32_t)seed, (uint32_t)(seed >> 32)));
+                mult = fscale / sqrtf(fmaxf(chi2_over_df_gamma(fdf, (uint32_t)i, (uint32_t)yi, (uint32_t)(yi >> 32),
+                                                               (uint32_t)seed, (uint32_t)(seed >> 32)), 1e-30f));
             const int total = ndf + dx;
             for (int c = 0; 4 * c < total; ++c) {
                 uint32_t ctr[4] = {(uint32_t)i, (uint32_t)c, (uint32_t)yi, (uint32_t)(yi >> 32)};
@@ -445,7 +448,7 @@ int rto_draw_samples(const float* xhat, int64_t N, int64_t y_index_base, int64_t
                     const int g = 4 * c + k;
                     if (g < ndf) {
                         zsum += nn[k] * nn[k];
-                        if (g == ndf - 1) mult = fscale / sqrtf(zsum / fdf);
+                        if (g == ndf - 1) mult = fscale / sqrtf(fmaxf(zsum * inv_df, 1e-30f));
                     } else if (g < total) {
                         const int d = g - ndf;
                         xs[((size_t)n * S + i) * dx + d] = xhat[n * dx + d] + mult * nn[k];

@@ -238,6 +238,7 @@ int make_sampler(rt_ctx* ctx, double scale, double df, uint64_t seed, SamplerArg
     sa.seed_lo = (uint32_t)seed;
     sa.seed_hi = (uint32_t)(seed >> 32);
     sa.df = (float)df;
+    sa.inv_df = (float)(1.0 / df);
     sa.scale = (float)scale;
     sa.ndf = (df == floor(df) && df <= 32.0) ? (int)df : 0;
     return RT_OK;

@@ -30,18 +30,24 @@ __device__ __forceinline__ float u01(uint32_t x) {
     return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
+// Two standard normals from two uniforms (Box-Muller) on the hardware's transcendental unit: v_log_f32 is log2, so
+// -2 ln u = (-2 ln 2) log2 u; v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so the angle 2 pi u is just u;
+// v_sqrt_f32.  Six quarter-rate instructions and four multiplies, where libm's logf / sincosf / sqrtf (argument
+// reduction, denormal and special-case handling for inputs that cannot occur here: u is in [2^-24, 1 - 2^-24]) took
+// about ninety: the sampler is per-sample work that does not shrink with the generator's width, and on a SIMD every VALU
+// cycle is a lost MFMA cycle.  r >= 3.4e-4 > 0.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float r = sqrtf(-2.0f * logf(u01(a)));
-    float sn, cs;
-    sincosf(6.28318530717958647692f * u01(b), &sn, &cs);
-    n0 = r * cs;
-    n1 = r * sn;
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u01(a)));
+    const float t = u01(b);
+    n0 = r * __builtin_amdgcn_cosf(t);
+    n1 = r * __builtin_amdgcn_sinf(t);
 }
 
 struct SamplerArgs {
     uint32_t seed_lo, seed_hi;
     int ndf;        // df if it is an integer in [1, 32], else 0 (gamma path)
     float df;
+    float inv_df;   // 1 / df
     float scale;
 };
 
@@ -79,8 +85,11 @@ template <typename Put>
 __device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx, uint32_t i,
                                             const float* xhat, int dx, Put put, int phase = 0, int nphase = 1) {
     const uint32_t ylo = (uint32_t)yidx, yhi = (uint32_t)(yidx >> 32);
+    // mult = scale / sqrt(chi2 / df) as scale * rsq(chi2 / df) (v_rsq_f32), the argument clamped away from 0: a chi2 of
+    // exactly 0 (the hardware cosine may return 0 next to a zero crossing) would make mult infinite and 0 * inf a NaN
+    // sample, which poisons the query point; clamped, such a draw lands ~1e15 scales out, G overflows and it weighs 0
     float zsum = 0.0f, mult = 0.0f;
-    if (sa.ndf == 0) mult = sa.scale / sqrtf(chi2_over_df_gamma(sa, i, ylo, yhi));
+    if (sa.ndf == 0) mult = sa.scale * __builtin_amdgcn_rsqf(fmaxf(chi2_over_df_gamma(sa, i, ylo, yhi), 1e-30f));
     const int total = sa.ndf + dx;
     for (int c = 0; 4 * c < total; ++c) {
         const bool mine = c % nphase == phase;
@@ -94,7 +103,7 @@ __device__ __forceinline__ void draw_sample(const SamplerArgs& sa, uint64_t yidx
             const int g = 4 * c + k;
             if (g < sa.ndf) {
                 zsum += n[k] * n[k];
-                if (g == sa.ndf - 1) mult = sa.scale / sqrtf(zsum / sa.df);
+                if (g == sa.ndf - 1) mult = sa.scale * __builtin_amdgcn_rsqf(fmaxf(zsum * sa.inv_df, 1e-30f));
             } else if (g < total && mine) {
                 const int d = g - sa.ndf;
                 put(d, xhat[d] + mult * n[k]);
