@@ -90,7 +90,7 @@ struct rt_ctx {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     HostMlp mlp[2];
-    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout, b_csend, b_crecv, b_sum;
+    DevBuf b_y, b_xhat, b_xs, b_out, b_partial, b_in, b_fout, b_csend, b_crecv, b_sum, b_mask;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<const void*, int>> lds_allowed;   // kernels whose dynamic-LDS limit has been raised, and to what
     size_t events_used = 0;
@@ -106,6 +106,8 @@ struct rt_ctx {
     ncclComm_t comm = nullptr;              // rt_comm_init
     int comm_rank = 0, comm_nranks = 1;
     int64_t max_launch_evals = 1ll << 28;   // sample-evals per fused-kernel launch (RT_IS_MAX_LAUNCH_EVALS overrides)
+    int jvp_masks = 1;                      // RT_JVP_MASKS (read by rt_ctx_create): 0 the Jacobian recomputes the primal per direction,
+                                            // 1 (default) whichever kernel is faster, 2 always the mask kernel (tests)
     int64_t cf_block_points = 1 << 20;      // query points per block of the Laplace estimator (RT_CF_BLOCK_POINTS overrides)
     double flops_acc = 0.0;
     uint64_t evals_acc = 0;
@@ -483,6 +485,15 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
     }
 }
 
+template <int HID, int NW = 4>
+int launch_jvp2(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp2_kernel<HID, NW>, lds));
+    hipLaunchKernelGGL((mlp_jvp2_kernel<HID, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, m, in, N, yout, J,
+                       (unsigned long long*)ctx->b_mask.p);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout, float* J) {
     if (which != RT_MLP_G && which != RT_MLP_H) return fail(ctx, RT_EINVAL, "which must be RT_MLP_G or RT_MLP_H");
     HostMlp& M = ctx->mlp[which];
@@ -491,9 +502,32 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
     if (N == 0) return RT_OK;
     if (M.nst != 2) return fail(ctx, RT_EUNSUPPORTED, "Jacobian needs hidden width <= 512 (64-column passes)");
     const Carve cv = carve_for(M.hid, 64, M.args.k0, M.args.in_dim, M.args.out_dim, 64 * M.nw);
-    const int64_t npass = ((N + 31) / 32) * M.args.in_dim;
+    const int64_t nblk = (N + 31) / 32;
+    const int64_t npass = nblk * M.args.in_dim;
     const int64_t gmax = (int64_t)ctx->cu_count * (M.nw == 1 ? 4 : 2);
     const int grid = (int)(npass < gmax ? npass : gmax);
+    {   // The primal once per block of rows (mlp_jvp2_kernel: 1 + floor(dx / 2) passes per block, whole blocks per
+        // workgroup) or once per direction (mlp_jvp_kernel: dx passes per block, dealt pass by pass): whichever leaves the
+        // busiest workgroup fewer passes.  RT_JVP_MASKS=0 (read by rt_ctx_create) keeps the per-direction kernel, =2 forces the other.
+        const int64_t g2 = nblk < gmax ? nblk : gmax;
+        const int64_t per_blk = 1 + M.args.in_dim / 2;
+        const int64_t busiest2 = ((nblk + g2 - 1) / g2) * per_blk, busiest1 = (npass + grid - 1) / grid;
+        if ((ctx->jvp_masks == 1 && M.args.in_dim >= 3 && busiest2 < busiest1) || (ctx->jvp_masks == 2 && M.args.in_dim >= 2)) {
+            const int rc = ensure(ctx, ctx->b_mask, (size_t)g2 * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long));
+            if (rc) return rc;
+            if (M.nw == 1) {
+                if (M.hid == 64) return launch_jvp2<64, 1>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                return launch_jvp2<128, 1>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+            }
+            if (M.nw == 2) return launch_jvp2<256, 2>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+            switch (M.hid) {
+                case 128: return launch_jvp2<128>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                case 256: return launch_jvp2<256>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                case 512: return launch_jvp2<512>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
+            }
+        }
+    }
     if (M.nw == 1) {
         if (M.hid == 64) return launch_jvp<64, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
         return launch_jvp<128, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
@@ -606,6 +640,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
         const long long n = atoll(v);
         if (n > 0) ctx->max_launch_evals = n;
     }
+    if (const char* v = getenv("RT_JVP_MASKS")) ctx->jvp_masks = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : 1;
     if (const char* v = getenv("RT_CF_BLOCK_POINTS")) {
         const long long n = atoll(v);
         if (n > 0) ctx->cf_block_points = n;
@@ -671,7 +706,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     free_mlp(ctx->mlp[0]);
     free_mlp(ctx->mlp[1]);
     DevBuf* bufs[] = {&ctx->b_y, &ctx->b_xhat, &ctx->b_xs, &ctx->b_out, &ctx->b_partial, &ctx->b_in, &ctx->b_fout,
-                      &ctx->b_csend, &ctx->b_crecv, &ctx->b_sum};
+                      &ctx->b_csend, &ctx->b_crecv, &ctx->b_sum, &ctx->b_mask};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->d_bal) {
         double cum[9];

@@ -484,6 +484,75 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const
     }
 }
 
+// The same Jacobian with the primal evaluated ONCE per block of 32 rows instead of once per input direction: the first
+// pass of a block is mlp_jvp_kernel's (primal + tangent e_0) and leaves, per hidden layer and thread, the 64-bit mask of
+// its positive primal pre-activations (mask_ws, [workgroup][hidden layer][thread]: written and read back by the same
+// thread); the following passes carry TWO tangent columns each (e_d in sample tile 0, e_{d+1} in tile 1) and take their
+// leaky-ReLU slopes from the masks.  1 + floor(in_dim / 2) passes per block instead of in_dim: the same MFMA chains on
+// the same operands, so J has the same bits.  A workgroup walks whole blocks (all directions of a block need its masks),
+// so the host picks this kernel only where that coarser split still wins (jvp_enqueue).
+template <int HID, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mlp_jvp2_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                           float* yout, float* J, unsigned long long* mask_ws) {
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int MS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Carve cv = carve_for(HID, MS, m.k0, m.in_dim, m.out_dim, NTHREADS);
+    char* x0 = smem + cv.x0;
+    char* act = smem + cv.act;
+    const float* part = (const float*)act;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    unsigned long long* mk = mask_ws + (size_t)blockIdx.x * (m.n_layers - 1) * NTHREADS;
+    for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t nblk = (N + 31) / 32;
+    const int sl = tid & 63, ph = tid >> 6;       // column slot, dimension phase
+#ifdef RT_STAMPS
+    Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
+#endif
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row = blk * 32 + (sl & 31);
+        // ---- first pass: primal rows (columns 0..31) + tangent e_0 (columns 32..63); leaves the masks --------
+        __syncthreads();
+        for (int d = ph; d < m.in_dim; d += NW) {
+            float v;
+            if (sl < 32) v = (row < N) ? in[row * m.in_dim + d] : 0.0f;
+            else v = (d == 0) ? 1.0f : 0.0f;
+            *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = v;
+        }
+        __syncthreads();
+        {
+            MlpPre<HID, NW> pre;
+            mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, mk);
+        }
+        if (row < N) {
+            if (sl < 32) {
+                if (yout)
+                    for (int d = ph; d < m.out_dim; d += NW) yout[row * m.out_dim + d] = mlp_out<MS>(m, part, d, sl);
+            } else {
+                for (int d = ph; d < m.out_dim; d += NW)
+                    J[(row * m.out_dim + d) * m.in_dim] = mlp_out_nobias<MS>(m, part, d, sl);
+            }
+        }
+        // ---- tangent-only passes: e_dir in columns 0..31, e_{dir+1} in columns 32..63 ---------------------------
+        for (int dir = 1; dir < m.in_dim; dir += 2) {
+            const int mydir = dir + (sl >> 5);                    // this column's direction (== in_dim: an idle tile)
+            __syncthreads();
+            for (int d = ph; d < m.in_dim; d += NW)
+                *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = (d == mydir) ? 1.0f : 0.0f;
+            __syncthreads();
+            {
+                MlpPre<HID, NW> pre;
+                mlp_core<HID, 2, 2, NW>(m, pre, x0, act, wave, lane ST_ARG, mk);
+            }
+            if (row < N && mydir < m.in_dim)
+                for (int d = ph; d < m.out_dim; d += NW)
+                    J[(row * m.out_dim + d) * m.in_dim + mydir] = mlp_out_nobias<MS>(m, part, d, sl);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Laplace (closed-form) estimator, the part after the three network evaluations (main_density_est.py:365-384; v2
 // roundtrip.py:341-366).  One wave per query point; everything in float64, like the reference's numpy:

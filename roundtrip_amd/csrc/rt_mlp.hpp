@@ -88,8 +88,9 @@ __device__ __forceinline__ void lrelu_quad(f32x16& t, int q, float alpha) {
 
 // FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
-// JVP: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.
-template <int NFT, int NST, bool FIRST = false, bool JVP = false>
+// JVP = 1: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.  JVP = 2: both tiles do (the
+// tangent-only passes of mlp_jvp2_kernel).
+template <int NFT, int NST, bool FIRST = false, int JVP = 0>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
                                            const f32x4 (&b)[NST], const f32x16* cinit = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -101,7 +102,7 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
             for (int st = 0; st < NST; ++st)
                 acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                     a[ft][e], b[st][e],
-                    (FIRST && e == 0) ? ((cinit && !(JVP && st == 1)) ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
+                    (FIRST && e == 0) ? ((cinit && !(JVP == 2 || (JVP == 1 && st == 1))) ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
 }
 
 // Source of one wave's packed weights for a layer: a buffer resource (SGPR descriptor) plus the lane's byte offset, so
@@ -141,7 +142,7 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], con
 }
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
-template <int NFT, int NST, bool JVP = false>
+template <int NFT, int NST, int JVP = 0>
 __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const WSrc& wl,
                                                  int ftt, int nkg, const char* bl, const f32x16* cinit) {
     f32x4 a[NFT], b[NST];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const 
 // of the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
 // the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
 // behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
-template <int NFT, int NST, bool FIRST = false, bool JVP = false>
+template <int NFT, int NST, bool FIRST = false, int JVP = 0>
 __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
                                            const WSrc& wl, int wstride, const char* bl, int kgn,
@@ -224,7 +225,7 @@ __device__ __forceinline__ void final_stage_act0(f32x16 (&acc)[NFT][NST], const 
 // MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
 // a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
 // ACT0: on return sample tile 0's accumulators already hold lrelu(pre-activation) (see final_stage_act0).
-template <int NFT, int NST, bool JVP = false, bool ACT0 = false>
+template <int NFT, int NST, int JVP = 0, bool ACT0 = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
                                           f32x4 (&a2)[NFT], const WSrc& wl,
                                           int ftt, int nkg, const char* bl, const f32x16* cinit, float alpha = 0.f) {
@@ -294,12 +295,18 @@ __device__ __forceinline__ void load_bias(f32x16 (&bv)[NFT], const float* __rest
 // the same lanes and registers, so the tangent's activation is lrelu'(t) * dt with no cross-lane traffic:
 // slope 1 where t > 0, alpha elsewhere.
 // ACT0: sample tile 0 is already activated (gemm_tile<..., ACT0>); only tile 1's arithmetic is left.
-template <int NFT, int NST, bool JVP = false, bool ACT0 = false>
-__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane) {
+// mk (JVP = 1, may be null): where this thread leaves the layer's slope mask — bit 16 ft + r set where the primal
+// pre-activation in register r of feature tile ft is > 0 — for the tangent-only passes that follow on the same rows
+// (JVP = 2: both tiles hold tangent pre-activations of the rows whose primal left the mask, in the same lanes and
+// registers, so the slope is again a per-register select; no primal is recomputed).
+template <int NFT, int NST, int JVP = 0, bool ACT0 = false>
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane,
+                                          unsigned long long* mk = nullptr) {
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
-    if constexpr (JVP) {
-        static_assert(NST == 2, "JVP pairs sample tile 0 (primal) with sample tile 1 (tangent)");
+    if constexpr (JVP == 1) {
+        static_assert(NST == 2 && NFT <= 4, "JVP pairs sample tile 0 (primal) with sample tile 1 (tangent)");
+        unsigned long long mask = 0;
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
             const int FT = wave * NFT + ft;
@@ -311,6 +318,30 @@ __device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, 
                     const float t = acc[ft][0][4 * q + e], dt = acc[ft][1][4 * q + e];
                     v0[e] = vmax(t, t * alpha);
                     v1[e] = (t > 0.0f) ? dt : dt * alpha;
+                    if (t > 0.0f) mask |= 1ull << (16 * ft + 4 * q + e);
+                }
+                *(f32x4*)(act + act_off<MS>(4 * FT + q, j, h)) = v0;
+                *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 + j, h)) = v1;
+            }
+        }
+        if (mk) *mk = mask;
+        return;
+    }
+    if constexpr (JVP == 2) {
+        static_assert(NST == 2 && NFT <= 4, "two tangent tiles");
+        const unsigned long long mask = *mk;
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const int FT = wave * NFT + ft;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pos = (mask >> (16 * ft + 4 * q + e)) & 1ull;
+                    const float d0 = acc[ft][0][4 * q + e], d1 = acc[ft][1][4 * q + e];
+                    v0[e] = pos ? d0 : d0 * alpha;
+                    v1[e] = pos ? d1 : d1 * alpha;
                 }
                 *(f32x4*)(act + act_off<MS>(4 * FT + q, j, h)) = v0;
                 *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 + j, h)) = v1;
@@ -798,17 +829,18 @@ __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act,
 // part[(w*out_dim + d)*MS + s], w = 0..3, hold the four K-quarter partial sums of output d for sample s
 // (bias not yet added).  Must be called by all 64 * NW threads of the workgroup.
 // pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
-template <int HID, int NST, bool JVP = false>
+template <int HID, int NST, int JVP = 0>
 constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 64, 128, 256, 512
 
-template <int HID, int NST, bool JVP = false, int NW = 4>
+template <int HID, int NST, int JVP = 0, int NW = 4>
 __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
     if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID, NW>(m, pre, wave, lane);
 }
 
-template <int HID, int NST, bool JVP = false, int NW = 4>
+// mask_ws (JVP = 1: optional, JVP = 2: required): this workgroup's slope masks, [hidden layer][thread] (see store_act).
+template <int HID, int NST, int JVP = 0, int NW = 4>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre, char* x0, char* act, int wave,
-                                         int lane ST_PARAM) {
+                                         int lane ST_PARAM, unsigned long long* mask_ws = nullptr) {
     static_assert(NW == 4 || (NST == 2 && ((NW == 1 && HID <= 128) || (NW == 2 && HID == 256))),
                   "one-wave workgroups: width <= 128; two-wave workgroups: width 256; both on 64-sample passes");
     constexpr int NFT = HID / (32 * NW);
@@ -853,7 +885,8 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
             prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
             if (l > 0) __syncthreads();   // all waves finished reading layer l's input
             ST(2)
-            store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
+            store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane,
+                                           mask_ws ? mask_ws + l * (64 * NW) + wave * 64 + lane : nullptr);
             load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
             ST(3)
             __syncthreads();
@@ -865,7 +898,8 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
         // live across the hidden layers' K loops)
         if (nhid > 1) __syncthreads();
         ST(2)
-        store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane);
+        store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane,
+                                       mask_ws ? mask_ws + (nhid - 1) * (64 * NW) + wave * 64 + lane : nullptr);
         if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
         ST(3)
         __syncthreads();

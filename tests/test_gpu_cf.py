@@ -105,6 +105,66 @@ def test_cf_estimate_dev_blocks_and_edges(make_nets, monkeypatch):
     assert np.array_equal(res[None], res["32"]) and np.array_equal(res[None], res["64"])
 
 
+@pytest.mark.parametrize("dx,dy,hid", [(2, 2, 512), (3, 6, 512), (5, 9, 512), (8, 21, 512), (20, 90, 512), (8, 21, 64),
+                                       (5, 9, 128), (3, 6, 256)])
+def test_jacobian_with_slope_masks_has_the_same_bits(make_nets, monkeypatch, dx, dy, hid):
+    """mlp_jvp2_kernel (the primal once per block of 32 rows, its leaky-ReLU slopes kept as bit masks for the tangent-only
+    passes that follow) against mlp_jvp_kernel (the primal recomputed per direction) and the C oracle's forward mode in
+    kernel order: G(x) and J bit for bit, on ragged row counts; and the Laplace estimate built on either."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    from test_gpu_parity import glorot_nets
+    if hid == 512:
+        gw, gb, hw, hb = make_nets(dx, dy)
+    else:
+        gw, gb = glorot_nets(dx, hid, dy, 7, n_hidden=5)
+        hw, hb = make_nets(dx, dy)[2:]
+    engines = {}
+    try:
+        for mode in ("0", "2"):
+            monkeypatch.setenv("RT_JVP_MASKS", mode)
+            engines[mode] = _lib.Engine(0)
+            engines[mode].set_mlp(G, gw, gb)
+            engines[mode].set_mlp(H, hw, hb)
+        og = c_oracle.OracleMlp(gw, gb)
+        rng = np.random.RandomState(dx + dy)
+        for n in (1, 31, 32, 33, 100):
+            x = (rng.standard_normal((n, dx)) * 1.5).astype(np.float32)
+            o0, j0 = engines["0"].mlp_jacobian(G, x)
+            o2, j2 = engines["2"].mlp_jacobian(G, x)
+            assert np.array_equal(o0, o2) and np.array_equal(j0, j2), n
+            if n <= 33:
+                wo, wj = og.jacobian(x, c_oracle.ORDER_KERNEL, nthreads=8)
+                assert np.array_equal(o2, wo) and np.array_equal(j2, wj), n
+        y = rng.standard_normal((150, dy)) * 0.4
+        assert np.array_equal(engines["0"].cf_estimate(y, 0.1), engines["2"].cf_estimate(y, 0.1))
+    finally:
+        for e in engines.values():
+            e.close()
+
+
+def test_jacobian_kernel_choice_on_a_large_call(make_nets, monkeypatch):
+    """The default picks the mask kernel where it leaves the busiest workgroup fewer passes (many rows, dx >= 3): 20 000
+    rows at 5/9 — same bits as the per-direction kernel, and as the oracle on a sample of the rows."""
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU on this machine")
+    gw, gb, hw, hb = make_nets(5, 9)
+    x = (np.random.RandomState(1).standard_normal((20000, 5)) * 1.5).astype(np.float32)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RT_JVP_MASKS", mode)
+        eng = _lib.Engine(0)
+        try:
+            eng.set_mlp(G, gw, gb)
+            res[mode] = eng.mlp_jacobian(G, x)
+        finally:
+            eng.close()
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
+    pick = np.random.RandomState(2).choice(20000, 40, replace=False)
+    wo, wj = c_oracle.OracleMlp(gw, gb).jacobian(x[pick], c_oracle.ORDER_KERNEL, nthreads=8)
+    assert np.array_equal(res["1"][0][pick], wo) and np.array_equal(res["1"][1][pick], wj)
+
+
 @pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
 def test_cf_estimate_golden(engine, name):
     f = np.load(os.path.join(GOLDEN, name + ".npz"))
