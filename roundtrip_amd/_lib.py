@@ -200,6 +200,11 @@ class Engine(object):
             raise ValueError("expected xhat of shape (%d, %d), got %r" % (N, dx, xhat.shape))
         return y, xhat, N, dx
 
+    @staticmethod
+    def _sds(sd_ys):
+        """The sd_y values of a several-sd call as a flat float64 array."""
+        return np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
+
     def is_estimate(self, y, xhat, sample_size, sd_y, scale, df=1.0, seed=0, log=True, y_index_base=0):
         y, xhat, N, dx = self._points(y, xhat)
         out = np.empty(N, dtype=np.float64)
@@ -246,7 +251,7 @@ class Engine(object):
     def is_estimate_multi(self, y, xhat, sample_size, sd_ys, scale, df=1.0, seed=0, log=True, y_index_base=0):
         """One sampler + G pass scored for every sd in sd_ys; returns (len(sd_ys), N)."""
         y, xhat, N, dx = self._points(y, xhat)
-        sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
+        sds = self._sds(sd_ys)
         out = np.empty((sds.size, N), dtype=np.float64)
         self._chk(self._lib.rt_is_estimate_multi(self._h, y.ctypes.data, xhat.ctypes.data, N, int(y_index_base),
                                                  int(sample_size), int(sds.size), sds.ctypes.data, float(scale),
@@ -263,7 +268,7 @@ class Engine(object):
     def is_pairs(self, y, xhat, sample_size, sd_ys, scale, e_lo, e_hi, df=1.0, seed=0, y_index_base=0):
         """Pairs [e_lo, e_hi) of every query point: (N, e_hi - e_lo, len(sd_ys), 2) float64."""
         y, xhat, N, dx = self._points(y, xhat)
-        sds = np.ascontiguousarray(sd_ys, dtype=np.float64).reshape(-1)
+        sds = self._sds(sd_ys)
         out = np.empty((N, max(0, int(e_hi) - int(e_lo)), sds.size, 2), dtype=np.float64)
         self._chk(self._lib.rt_is_pairs(self._h, y.ctypes.data, xhat.ctypes.data, C.c_int64(N),
                                         C.c_int64(int(y_index_base)), C.c_int64(int(sample_size)), int(sds.size),
