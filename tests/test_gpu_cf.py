@@ -165,6 +165,53 @@ def test_jacobian_kernel_choice_on_a_large_call(make_nets, monkeypatch):
     assert np.array_equal(res["1"][0][pick], wo) and np.array_equal(res["1"][1][pick], wj)
 
 
+@pytest.mark.parametrize("case_seed", range(24))
+def test_cf_random_shapes_against_the_reference_formulas(engine, case_seed):
+    """Random generator / encoder shapes (dims 1..40, hidden widths 16..512 in any mix, 2..6 layers, sd 0.03..2, ragged
+    N): rt_cf_estimate against the reference's formulas on the C oracle's kernel-order network outputs."""
+    rng = np.random.RandomState(1000 + case_seed)
+    dx, dy = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+    gh = [int(rng.choice([16, 50, 64, 100, 128, 200, 256, 300, 512])) for _ in range(rng.randint(1, 6))]
+    hh = [int(rng.choice([32, 64, 128, 256])) for _ in range(rng.randint(1, 4))]
+    gw, gb = is_ref.glorot_mlp([dx] + gh + [dy], rng)
+    gb = [rng.uniform(-0.1, 0.1, size=b.shape).astype(np.float32) for b in gb]
+    hw, hb = is_ref.glorot_mlp([dy] + hh + [dx], rng)
+    sd = float(10.0 ** rng.uniform(-1.5, 0.3))
+    n = int(rng.choice([1, 5, 32, 33, 70]))
+    try:
+        engine.set_mlp(G, gw, gb)
+    except _lib.RtError as e:
+        assert e.code == 4 and max(gh) <= 1024          # RT_EUNSUPPORTED: the LDS budget, with its own test elsewhere
+        pytest.skip("shape outside the LDS budget: %s" % e)
+    engine.set_mlp(H, hw, hb)
+    y = rng.standard_normal((n, dy)) * 0.5
+    og, oh = c_oracle.OracleMlp(gw, gb), c_oracle.OracleMlp(hw, hb)
+    x_ = oh.forward(y.astype(np.float32), c_oracle.ORDER_KERNEL, nthreads=8).astype(np.float64)
+    y__, J = og.jacobian(x_, c_oracle.ORDER_KERNEL, nthreads=8)
+    want = cf_reference_formulas(y, x_, y__.astype(np.float64), J.astype(np.float64), sd, True)
+    got = engine.cf_estimate(y, sd, log=True)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9, err_msg=str((dx, dy, gh, hh, sd, n)))
+
+
+@pytest.mark.parametrize("dx,dy,hid", [(1, 1, 128), (1, 7, 512), (64, 70, 256), (100, 128, 512), (128, 30, 256)])
+def test_cf_extreme_dims(engine, dx, dy, hid):
+    """The smallest dims and the largest the kernels take (dx = 128: a 128 x 128 float64 factorisation in 128 KB of LDS,
+    two rows per lane in the column loops)."""
+    from test_gpu_parity import glorot_nets
+    gw, gb = glorot_nets(dx, hid, dy, 3, n_hidden=2)
+    hw, hb = glorot_nets(dy, 128, dx, 4, n_hidden=2)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    rng = np.random.RandomState(dx)
+    y = rng.standard_normal((9, dy)) * 0.5
+    og, oh = c_oracle.OracleMlp(gw, gb), c_oracle.OracleMlp(hw, hb)
+    x_ = oh.forward(y.astype(np.float32), c_oracle.ORDER_KERNEL, nthreads=8).astype(np.float64)
+    y__, J = og.jacobian(x_, c_oracle.ORDER_KERNEL, nthreads=8)
+    for sd in (0.5, 0.05):
+        want = cf_reference_formulas(y, x_, y__.astype(np.float64), J.astype(np.float64), sd, True)
+        np.testing.assert_allclose(engine.cf_estimate(y, sd, log=True), want, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
 def test_cf_estimate_golden(engine, name):
     f = np.load(os.path.join(GOLDEN, name + ".npz"))
