@@ -545,7 +545,7 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
 // order, y -> float32 feed -> H forward (xhat) -> G forward + Jacobian at xhat (mlp_jvp_kernel) -> cf_finish_kernel.
 // The Jacobians never leave the device: a block's (<= 256 MB of float32, N_blk x dy x dx) is written by one kernel and
 // read by the next, which at the reference shapes is < 0.5 % of the Jacobian kernel's own time (YearPredictionMSD 20/90:
-// 7.2 KB per point against 40 rows x 4.8 MFLOP).  Buffers are sized once, before anything is enqueued.
+// 7.2 KB per point against 22 generator rows x 4.8 MFLOP).  Buffers are sized once, before anything is enqueued.
 int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_flag, double* out) {
     HostMlp& G = ctx->mlp[RT_MLP_G];
     HostMlp& H = ctx->mlp[RT_MLP_H];
