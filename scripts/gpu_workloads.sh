@@ -26,3 +26,7 @@ done
 run hepmass_g1024 400 --workload hepmass --g-units 1024 --points 2048 --steps 2 --warmup 1 --cpu-points 8 --cpu-points-numpy 2 || exit 1
 run full_bank 900 --workload bank --steps 1 --warmup 1 --no-live-traffic --cpu-points 48 --cpu-points-numpy 16 || exit 1
 run full_hepmass 900 --workload hepmass --steps 1 --warmup 1 --no-live-traffic --cpu-points 48 --cpu-points-numpy 16 || exit 1
+# the per-GPU shares of the 8-GPU configurations at full size (5e9 sample-evals each: 19-20 bounded launches, ~160 s)
+run full_arem 900 --workload arem --steps 1 --warmup 0 --no-live-traffic --cpu-points 48 --cpu-points-numpy 16 || exit 1
+run full_casp 900 --workload casp --steps 1 --warmup 0 --no-live-traffic --cpu-points 48 --cpu-points-numpy 16 || exit 1
+run full_ypmsd_weak 900 --workload ypmsd-weak --steps 1 --warmup 0 --no-live-traffic --cpu-points 48 --cpu-points-numpy 16 || exit 1

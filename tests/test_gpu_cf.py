@@ -212,6 +212,27 @@ def test_cf_extreme_dims(engine, dx, dy, hid):
         np.testing.assert_allclose(engine.cf_estimate(y, sd, log=True), want, rtol=1e-9, atol=1e-9)
 
 
+def test_cf_full_size_properties(engine, make_nets):
+    """BASELINE-size call (200 000 HEPMASS-shaped points: several blocks of the Jacobian buffer, the slope-mask kernel
+    on every one of them) through size-independent properties: every result finite; 300 points picked at random and
+    evaluated alone have the same bits; log and linear agree through the reference's extra sd^dy; the device-side mean and
+    standard error of the results have numpy's bits."""
+    gw, gb, hw, hb = make_nets(8, 21)
+    engine.set_mlp(G, gw, gb)
+    engine.set_mlp(H, hw, hb)
+    n, sd = 200000, 0.5
+    y = np.random.RandomState(42).standard_normal((n, 21)).astype(np.float32).astype(np.float64)
+    got = engine.cf_estimate(y, sd, log=True)
+    assert got.shape == (n,) and np.all(np.isfinite(got))
+    pick = np.sort(np.random.RandomState(1).choice(n, 300, replace=False))
+    assert np.array_equal(engine.cf_estimate(y[pick], sd, log=True), got[pick])
+    lin = engine.cf_estimate(y[:5000], sd, log=False)
+    ok = lin > 1e-300
+    np.testing.assert_allclose(np.log(lin[ok]) - 21 * np.log(sd), got[:5000][ok], rtol=1e-9, atol=1e-9)
+    mean, se = engine.mean_stderr(got)
+    assert mean == np.mean(got) and se == np.std(got) / np.sqrt(n)
+
+
 @pytest.mark.parametrize("name", ["indep_gmm_2_2", "arem_3_6", "ypmsd_20_90", "df3_biased_2_2"])
 def test_cf_estimate_golden(engine, name):
     f = np.load(os.path.join(GOLDEN, name + ".npz"))
