@@ -80,6 +80,7 @@ struct HostMlp {
     std::vector<int> dims;
     std::vector<void*> dev;   // device allocations to free
     MlpArgs args;
+    MlpArgs args0;            // args with all-zero hidden-layer biases: the tangent-only passes (mlp_jvp_rest_kernel)
     double flops_per_row = 0.0;
 };
 
@@ -486,10 +487,17 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
 }
 
 template <int HID, int NW = 4>
-int launch_jvp2(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
-    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp2_kernel<HID, NW>, lds));
-    hipLaunchKernelGGL((mlp_jvp2_kernel<HID, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, m, in, N, yout, J,
-                       (unsigned long long*)ctx->b_mask.p);
+int launch_jvp2(rt_ctx* ctx, const HostMlp& M, const float* in, int64_t N, float* yout, float* J, int64_t gmax, int lds) {
+    const int64_t nblk = (N + 31) / 32, nrest = nblk * (M.args.in_dim / 2);
+    unsigned long long* masks = (unsigned long long*)ctx->b_mask.p;
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_first_kernel<HID, NW>, lds));
+    hipLaunchKernelGGL((mlp_jvp_first_kernel<HID, NW>), dim3((unsigned)(nblk < gmax ? nblk : gmax)), dim3(64 * NW), lds,
+                       ctx->stream, M.args, in, N, yout, J, masks);
+    HIPCHK(ctx, hipGetLastError());
+    if (nrest == 0) return RT_OK;
+    HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_rest_kernel<HID, NW>, lds));
+    hipLaunchKernelGGL((mlp_jvp_rest_kernel<HID, NW>), dim3((unsigned)(nrest < gmax ? nrest : gmax)), dim3(64 * NW), lds,
+                       ctx->stream, M.args0, N, J, (const unsigned long long*)masks);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -506,24 +514,24 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
     const int64_t npass = nblk * M.args.in_dim;
     const int64_t gmax = (int64_t)ctx->cu_count * (M.nw == 1 ? 4 : 2);
     const int grid = (int)(npass < gmax ? npass : gmax);
-    {   // The primal once per block of rows (mlp_jvp2_kernel: 1 + floor(dx / 2) passes per block, whole blocks per
-        // workgroup) or once per direction (mlp_jvp_kernel: dx passes per block, dealt pass by pass): whichever leaves the
-        // busiest workgroup fewer passes.  RT_JVP_MASKS=0 (read by rt_ctx_create) keeps the per-direction kernel, =2 forces the other.
-        const int64_t g2 = nblk < gmax ? nblk : gmax;
-        const int64_t per_blk = 1 + M.args.in_dim / 2;
-        const int64_t busiest2 = ((nblk + g2 - 1) / g2) * per_blk, busiest1 = (npass + grid - 1) / grid;
+    {   // The primal once per block of rows (mlp_jvp_first_kernel + mlp_jvp_rest_kernel: 1 + floor(dx / 2) passes per block)
+        // or once per direction (mlp_jvp_kernel: dx passes per block): whichever leaves the busiest workgroup fewer
+        // passes.  RT_JVP_MASKS=0 (read by rt_ctx_create) keeps the per-direction kernel, =2 forces the other.
+        const int64_t nrest = nblk * (M.args.in_dim / 2);
+        const int64_t g1 = nblk < gmax ? nblk : gmax, g2 = nrest < gmax ? nrest : gmax;
+        const int64_t busiest2 = (nblk + g1 - 1) / g1 + (g2 ? (nrest + g2 - 1) / g2 : 0), busiest1 = (npass + grid - 1) / grid;
         if ((ctx->jvp_masks == 1 && M.args.in_dim >= 3 && busiest2 < busiest1) || (ctx->jvp_masks == 2 && M.args.in_dim >= 2)) {
-            const int rc = ensure(ctx, ctx->b_mask, (size_t)g2 * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long));
+            const int rc = ensure(ctx, ctx->b_mask, (size_t)nblk * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long));
             if (rc) return rc;
             if (M.nw == 1) {
-                if (M.hid == 64) return launch_jvp2<64, 1>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
-                return launch_jvp2<128, 1>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                if (M.hid == 64) return launch_jvp2<64, 1>(ctx, M, in, N, yout, J, gmax, cv.total);
+                return launch_jvp2<128, 1>(ctx, M, in, N, yout, J, gmax, cv.total);
             }
-            if (M.nw == 2) return launch_jvp2<256, 2>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+            if (M.nw == 2) return launch_jvp2<256, 2>(ctx, M, in, N, yout, J, gmax, cv.total);
             switch (M.hid) {
-                case 128: return launch_jvp2<128>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
-                case 256: return launch_jvp2<256>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
-                case 512: return launch_jvp2<512>(ctx, M.args, in, N, yout, J, (int)g2, cv.total);
+                case 128: return launch_jvp2<128>(ctx, M, in, N, yout, J, gmax, cv.total);
+                case 256: return launch_jvp2<256>(ctx, M, in, N, yout, J, gmax, cv.total);
+                case 512: return launch_jvp2<512>(ctx, M, in, N, yout, J, gmax, cv.total);
                 default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
             }
         }
@@ -824,6 +832,15 @@ int rt_set_mlp(rt_ctx* ctx, int which, int n_layers, const int32_t* dims, const 
         M.dev.push_back(dws);
         HIPCHK(ctx, hipMemcpy(dws, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
         M.args.wsmall = (const float*)dws;
+    }
+    {   // the tangent passes' view of the net: same weights, zero biases on the hidden layers
+        void* dz = nullptr;
+        const size_t zb = (size_t)((hid + 31) / 32) * 32 * sizeof(float);
+        HIPCHK(ctx, hipMalloc(&dz, zb));
+        M.dev.push_back(dz);
+        HIPCHK(ctx, hipMemset(dz, 0, zb));
+        M.args0 = M.args;
+        for (int l = 0; l + 1 < n_layers; ++l) M.args0.bp[l] = (const float*)dz;
     }
     M.set = true;
     return RT_OK;

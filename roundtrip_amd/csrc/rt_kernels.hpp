@@ -484,16 +484,19 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const
     }
 }
 
-// The same Jacobian with the primal evaluated ONCE per block of 32 rows instead of once per input direction: the first
-// pass of a block is mlp_jvp_kernel's (primal + tangent e_0) and leaves, per hidden layer and thread, the 64-bit mask of
-// its positive primal pre-activations (mask_ws, [workgroup][hidden layer][thread]: written and read back by the same
-// thread); the following passes carry TWO tangent columns each (e_d in sample tile 0, e_{d+1} in tile 1) and take their
-// leaky-ReLU slopes from the masks.  1 + floor(in_dim / 2) passes per block instead of in_dim: the same MFMA chains on
-// the same operands, so J has the same bits.  A workgroup walks whole blocks (all directions of a block need its masks),
-// so the host picks this kernel only where that coarser split still wins (jvp_enqueue).
+// The same Jacobian with the primal evaluated ONCE per block of 32 rows instead of once per input direction, as two
+// kernels.  mlp_jvp_first_kernel: one pass per block of rows — mlp_jvp_kernel's pass for direction 0 (primal + tangent e_0) —
+// which also leaves, per hidden layer and thread, the 64-bit mask of its positive primal pre-activations
+// (mask_ws[block of rows][hidden layer][thread]).  mlp_jvp_rest_kernel: the other directions, TWO tangent columns per pass
+// (e_d in sample tile 0, e_{d+1} in tile 1, d = 1, 3, ...), their leaky-ReLU slopes taken from the block's masks — on the
+// fused kernel's skewed layer schedule (rt_mlp.hpp skew_layer, MASKED: tile B two k-groups behind tile A, the mask select
+// as the one VALU cluster per tile), with all-zero hidden biases (m0); passes are dealt one by one like everywhere else.
+// 1 + floor(in_dim / 2) passes per block instead of in_dim: the same MFMA chains on the same operands, so J has the
+// same bits.  (One kernel doing both kinds of pass spilled registers at width 512: the plain and the skewed schedule's
+// live ranges add up.)
 template <int HID, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void mlp_jvp2_kernel(const MlpArgs m, const float* in, int64_t N,
-                                                           float* yout, float* J, unsigned long long* mask_ws) {
+__global__ __launch_bounds__(64 * NW) void mlp_jvp_first_kernel(const MlpArgs m, const float* in, int64_t N,
+                                                                float* yout, float* J, unsigned long long* mask_ws) {
     constexpr int NTHREADS = 64 * NW;
     constexpr int MS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -504,16 +507,11 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp2_kernel(const MlpArgs m, cons
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    unsigned long long* mk = mask_ws + (size_t)blockIdx.x * (m.n_layers - 1) * NTHREADS;
     for (int i = tid; i < m.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t nblk = (N + 31) / 32;
     const int sl = tid & 63, ph = tid >> 6;       // column slot, dimension phase
-#ifdef RT_STAMPS
-    Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
-#endif
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t row = blk * 32 + (sl & 31);
-        // ---- first pass: primal rows (columns 0..31) + tangent e_0 (columns 32..63); leaves the masks --------
         __syncthreads();
         for (int d = ph; d < m.in_dim; d += NW) {
             float v;
@@ -522,10 +520,11 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp2_kernel(const MlpArgs m, cons
             *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = v;
         }
         __syncthreads();
-        {
-            MlpPre<HID, NW> pre;
-            mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, mk);
-        }
+#ifdef RT_STAMPS
+        Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
+#endif
+        MlpPre<HID, NW> pre;
+        mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, mask_ws + (size_t)blk * (m.n_layers - 1) * NTHREADS);
         if (row < N) {
             if (sl < 32) {
                 if (yout)
@@ -535,21 +534,44 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp2_kernel(const MlpArgs m, cons
                     J[(row * m.out_dim + d) * m.in_dim] = mlp_out_nobias<MS>(m, part, d, sl);
             }
         }
-        // ---- tangent-only passes: e_dir in columns 0..31, e_{dir+1} in columns 32..63 ---------------------------
-        for (int dir = 1; dir < m.in_dim; dir += 2) {
-            const int mydir = dir + (sl >> 5);                    // this column's direction (== in_dim: an idle tile)
-            __syncthreads();
-            for (int d = ph; d < m.in_dim; d += NW)
-                *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = (d == mydir) ? 1.0f : 0.0f;
-            __syncthreads();
-            {
-                MlpPre<HID, NW> pre;
-                mlp_core<HID, 2, 2, NW>(m, pre, x0, act, wave, lane ST_ARG, mk);
-            }
-            if (row < N && mydir < m.in_dim)
-                for (int d = ph; d < m.out_dim; d += NW)
-                    J[(row * m.out_dim + d) * m.in_dim + mydir] = mlp_out_nobias<MS>(m, part, d, sl);
-        }
+    }
+}
+
+template <int HID, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mlp_jvp_rest_kernel(const MlpArgs m0, int64_t N, float* J,
+                                                               const unsigned long long* mask_ws) {
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int MS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Carve cv = carve_for(HID, MS, m0.k0, m0.in_dim, m0.out_dim, NTHREADS);
+    char* x0 = smem + cv.x0;
+    char* act = smem + cv.act;
+    const float* part = (const float*)act;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    for (int i = tid; i < m0.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int npair = m0.in_dim / 2;                              // passes per block of rows: directions (1, 2), (3, 4), ...
+    const int64_t npass = ((N + 31) / 32) * npair;
+    const int sl = tid & 63, ph = tid >> 6;
+    for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
+        const int64_t blk = ps / npair;
+        const int mydir = 1 + 2 * (int)(ps - blk * npair) + (sl >> 5);    // this column's direction (== in_dim: an idle tile)
+        const int64_t row = blk * 32 + (sl & 31);
+        __syncthreads();
+        for (int d = ph; d < m0.in_dim; d += NW)
+            *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = (d == mydir) ? 1.0f : 0.0f;
+        __syncthreads();
+#ifdef RT_STAMPS
+        Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
+#endif
+        MlpPre<HID, NW> pre;
+        mlp_prefetch<HID, 2, 2, NW>(m0, pre, wave, lane);
+        mlp_core<HID, 2, 2, NW>(m0, pre, x0, act, wave, lane ST_ARG,
+                                const_cast<unsigned long long*>(mask_ws) + (size_t)blk * (m0.n_layers - 1) * NTHREADS);
+        if (row < N && mydir < m0.in_dim)
+            for (int d = ph; d < m0.out_dim; d += NW)
+                J[(row * m0.out_dim + d) * m0.in_dim + mydir] = mlp_out_nobias<MS>(m0, part, d, sl);
     }
 }
 

@@ -89,7 +89,7 @@ __device__ __forceinline__ void lrelu_quad(f32x16& t, int q, float alpha) {
 // FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
 // JVP = 1: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.  JVP = 2: both tiles do (the
-// tangent-only passes of mlp_jvp2_kernel).
+// tangent-only passes of mlp_jvp_rest_kernel).
 template <int NFT, int NST, bool FIRST = false, int JVP = 0>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
                                            const f32x4 (&b)[NST], const f32x16* cinit = nullptr) {
@@ -433,6 +433,22 @@ __device__ __forceinline__ void lrelu_tile(f32x16 (&acc)[NFT][2], float alpha) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The tangent passes' counterpart of lrelu_tile (mlp_jvp_rest_kernel): the tile holds tangent pre-activations; element r of
+// feature tile ft keeps slope 1 where bit 16 ft + r of `mask` — the sign of the PRIMAL pre-activation in the same lane and
+// register, left by the rows' first pass (store_act) — is set, alpha elsewhere.  One VALU cluster, like lrelu_tile.
+template <int NFT, int TILE>
+__device__ __forceinline__ void mask_tile(f32x16 (&acc)[NFT][2], float alpha, unsigned long long mask) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[ft][TILE][r];
+            acc[ft][TILE][r] = ((mask >> (16 * ft + r)) & 1ull) ? d : d * alpha;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Bias of one register quad (idx = 4*ft + q) of tile TILE, loaded straight INTO the accumulators: a layer's first MFMA
 // then accumulates onto it like any other (no separate bias registers, no special first k-step).  bias: the layer's
 // padded bias vector as a buffer resource; voff: this lane's byte offset (32*wave*NFT + 4h)*4.
@@ -562,10 +578,12 @@ __device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32
 // activations, not yet stored, and every wave is done reading tile B's image.  On return the same holds one layer on
 // (wn / bias_n = the next layer's weights and bias; when there is none the caller passes this layer's again and
 // ignores the result).
-template <int NFT, int NKG>
+// MASKED (tangent-only passes of the Jacobian kernel): the two clusters select slopes by `mk`, this layer's mask (mask_tile).
+template <int NFT, int NKG, bool MASKED = false>
 __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x4 (&bA)[6],
                                            const WSrc& wl, const WSrc& wn, const BiasSrc& bias, const BiasSrc& bias_n,
-                                           int wstride, const LdsBase& bl, char* st_base, float alpha ST_PARAM) {
+                                           int wstride, const LdsBase& bl, char* st_base, float alpha ST_PARAM,
+                                           unsigned long long mk = 0) {
     static_assert(NKG >= 8, "the next layer's first weights are requested into wh from stage NKG-3 on");
     f32x4 w[6][NFT], bB[6];
     // ---- stage 0: A only; previous layer's tile B stored in the shadow; requests w[3], bA[3] ---------------------
@@ -594,7 +612,7 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     ST(5)
     __syncthreads();   // Q: every wave has read all of tile A's image (its last operand fed stage NKG-1)
     ST(4)
-    lrelu_tile<NFT, 0>(acc, alpha);
+    if constexpr (MASKED) mask_tile<NFT, 0>(acc, alpha, mk); else lrelu_tile<NFT, 0>(acc, alpha);
     ST(12)
     // ---- stage NKG: B only; tile A stored in the shadow ------------------------------------------------------
     //      (the next layer's bias goes into tile A's accumulators BLAG quads behind the stores that empty them)
@@ -613,7 +631,7 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     ST(11)
     __syncthreads();   // S: every wave has read all of tile B's image
     ST(4)
-    lrelu_tile<NFT, 1>(acc, alpha);
+    if constexpr (MASKED) mask_tile<NFT, 1>(acc, alpha, mk); else lrelu_tile<NFT, 1>(acc, alpha);
     ST(13)
 }
 
@@ -641,9 +659,10 @@ __device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID, NW>&
 // closing barrier still to come (the caller requests the output layer's weights first).
 // Layer 0 (K = k0, a few k-groups) is the same dance without the skew: all k-groups but the last for both tiles, then
 // the last one: tile A's MFMAs, A's leaky-ReLU cluster, tile B's MFMAs with A's stores behind them, barrier, B's cluster.
-template <int HID, int NW = 4>
+// MASKED: see skew_layer; mask_ws = this workgroup's slope masks, [hidden layer][thread].
+template <int HID, int NW = 4, bool MASKED = false>
 __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>& pre, const char* x0, char* act, int wave,
-                                              int lane ST_PARAM) {
+                                              int lane ST_PARAM, const unsigned long long* mask_ws = nullptr) {
     constexpr int NFT = HID / (32 * NW), FTT = HID / 32, NKG = HID / 8;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
@@ -685,7 +704,8 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>&
 #pragma unroll
                 for (int ft = 0; ft < NFT; ++ft) wh[g][ft] = wload(wl, g, FTT * 64, ft);
         }
-        lrelu_tile<NFT, 0>(acc, m.alpha);
+        if constexpr (MASKED) mask_tile<NFT, 0>(acc, m.alpha, mask_ws[wave * 64 + lane]);
+        else lrelu_tile<NFT, 0>(acc, m.alpha);
         // (layer 1's bias goes into tile A's accumulators BLAG quads behind the stores that empty them; harmless if
         // there is no layer 1)
         skew_edge_stage<NFT, 1>(acc, a, bx[1], [&](int idx) {
@@ -701,11 +721,16 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>&
         bA[1] = lds_operand(bl, 2048);
         bA[2] = lds_operand(bl, 4096);
     }
-    lrelu_tile<NFT, 1>(acc, m.alpha);
+    if constexpr (MASKED) mask_tile<NFT, 1>(acc, m.alpha, mask_ws[wave * 64 + lane]);
+    else lrelu_tile<NFT, 1>(acc, m.alpha);
     ST(1)
     for (int l = 1; l < nhid; ++l) {
         const int ln = (l + 1 < nhid) ? l + 1 : l;
         const WSrc wn = make_wsrc(m.wp[ln] + (wave * NFT) * 256, lane);
+        if constexpr (MASKED)
+            skew_layer<NFT, NKG, true>(acc, wh, bA, wl, wn, make_bias(m.bp[l], bias_voff), make_bias(m.bp[ln], bias_voff),
+                                       FTT * 64, bl, st_base, m.alpha ST_ARG, mask_ws[l * (64 * NW) + wave * 64 + lane]);
+        else
         skew_layer<NFT, NKG>(acc, wh, bA, wl, wn, make_bias(m.bp[l], bias_voff), make_bias(m.bp[ln], bias_voff),
                              FTT * 64, bl, st_base, m.alpha ST_ARG);
         wl = wn;
@@ -830,7 +855,8 @@ __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act,
 // (bias not yet added).  Must be called by all 64 * NW threads of the workgroup.
 // pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
 template <int HID, int NST, int JVP = 0>
-constexpr bool mlp_is_skewed() { return (NST == 2) && !JVP; }   // 64-sample passes: widths 64, 128, 256, 512
+constexpr bool mlp_is_skewed() { return (NST == 2) && JVP != 1; }   // 64-sample passes: widths 64, 128, 256, 512; JVP = 2
+                                                                    // (two tangent tiles): the same schedule with mask_tile
 
 template <int HID, int NST, int JVP = 0, int NW = 4>
 __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
@@ -859,7 +885,8 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
     f32x4 wsm[2 * KQ * NQL];
     constexpr bool SKEWED = mlp_is_skewed<HID, NST, JVP>();
     if constexpr (SKEWED) {
-        hidden_skewed<HID, NW>(m, pre, x0, act, wave, lane ST_ARG);
+        if constexpr (JVP == 2) hidden_skewed<HID, NW, true>(m, pre, x0, act, wave, lane ST_ARG, mask_ws);
+        else hidden_skewed<HID, NW>(m, pre, x0, act, wave, lane ST_ARG);
         ST(1)
         if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
         __syncthreads();

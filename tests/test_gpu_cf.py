@@ -108,7 +108,7 @@ def test_cf_estimate_dev_blocks_and_edges(make_nets, monkeypatch):
 @pytest.mark.parametrize("dx,dy,hid", [(2, 2, 512), (3, 6, 512), (5, 9, 512), (8, 21, 512), (20, 90, 512), (8, 21, 64),
                                        (5, 9, 128), (3, 6, 256)])
 def test_jacobian_with_slope_masks_has_the_same_bits(make_nets, monkeypatch, dx, dy, hid):
-    """mlp_jvp2_kernel (the primal once per block of 32 rows, its leaky-ReLU slopes kept as bit masks for the tangent-only
+    """mlp_jvp_first_kernel + mlp_jvp_rest_kernel (the primal once per block of 32 rows, its leaky-ReLU slopes kept as bit masks for the tangent-only
     passes that follow) against mlp_jvp_kernel (the primal recomputed per direction) and the C oracle's forward mode in
     kernel order: G(x) and J bit for bit, on ragged row counts; and the Laplace estimate built on either."""
     if not os.path.exists("/dev/kfd"):
