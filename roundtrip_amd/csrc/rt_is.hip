@@ -520,8 +520,10 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
         const int64_t nrest = nblk * (M.args.in_dim / 2);
         const int64_t g1 = nblk < gmax ? nblk : gmax, g2 = nrest < gmax ? nrest : gmax;
         const int64_t busiest2 = (nblk + g1 - 1) / g1 + (g2 ? (nrest + g2 - 1) / g2 : 0), busiest1 = (npass + grid - 1) / grid;
-        if ((ctx->jvp_masks == 1 && M.args.in_dim >= 3 && busiest2 < busiest1) || (ctx->jvp_masks == 2 && M.args.in_dim >= 2)) {
-            const int rc = ensure(ctx, ctx->b_mask, (size_t)nblk * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long));
+        const size_t mask_bytes = (size_t)nblk * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long);
+        if ((ctx->jvp_masks == 1 && M.args.in_dim >= 3 && busiest2 < busiest1 && mask_bytes <= (1ull << 30)) ||
+            (ctx->jvp_masks == 2 && M.args.in_dim >= 2)) {
+            const int rc = ensure(ctx, ctx->b_mask, mask_bytes);
             if (rc) return rc;
             if (M.nw == 1) {
                 if (M.hid == 64) return launch_jvp2<64, 1>(ctx, M, in, N, yout, J, gmax, cv.total);
@@ -569,6 +571,10 @@ int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_fla
     if (N == 0) return RT_OK;
     int64_t per = (int64_t)((256ull << 20) / ((size_t)dx * dy * sizeof(float)));
     if (per > ctx->cf_block_points) per = ctx->cf_block_points;
+    {   // ... and <= 256 MB of the Jacobian kernels' slope masks (8 B per thread and hidden layer for every 32 rows)
+        const int64_t per_mask = (int64_t)((256ull << 20) / ((size_t)(G.n_layers - 1) * 64 * G.nw * sizeof(unsigned long long))) * 32;
+        if (per > per_mask) per = per_mask;
+    }
     per &= ~(int64_t)31;                       // whole 32-row blocks of the Jacobian kernel
     if (per < 32) per = 32;
     if (per > N) per = N;
