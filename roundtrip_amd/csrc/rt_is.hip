@@ -228,9 +228,9 @@ int launch_fwd(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float*
 }
 
 template <int HID, int NW = 4>
-int launch_jvp(rt_ctx* ctx, const MlpArgs& m, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
+int launch_jvp(rt_ctx* ctx, const HostMlp& M, const float* in, int64_t N, float* yout, float* J, int grid, int lds) {
     HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_kernel<HID, NW>, lds));
-    hipLaunchKernelGGL((mlp_jvp_kernel<HID, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, m, in, N, yout, J);
+    hipLaunchKernelGGL((mlp_jvp_kernel<HID, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, M.args, M.args0.bp[0], in, N, yout, J);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -488,11 +488,11 @@ int fwd_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* out) 
 
 template <int HID, int NW = 4>
 int launch_jvp2(rt_ctx* ctx, const HostMlp& M, const float* in, int64_t N, float* yout, float* J, int64_t gmax, int lds) {
-    const int64_t nblk = (N + 31) / 32, nrest = nblk * (M.args.in_dim / 2);
+    const int64_t nblk = (N + 31) / 32, nrest = (nblk * (M.args.in_dim - 1) + 1) / 2;
     unsigned long long* masks = (unsigned long long*)ctx->b_mask.p;
     HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_first_kernel<HID, NW>, lds));
     hipLaunchKernelGGL((mlp_jvp_first_kernel<HID, NW>), dim3((unsigned)(nblk < gmax ? nblk : gmax)), dim3(64 * NW), lds,
-                       ctx->stream, M.args, in, N, yout, J, masks);
+                       ctx->stream, M.args, M.args0.bp[0], in, N, yout, J, masks);
     HIPCHK(ctx, hipGetLastError());
     if (nrest == 0) return RT_OK;
     HIPCHK(ctx, allow_lds(ctx, (const void*)mlp_jvp_rest_kernel<HID, NW>, lds));
@@ -514,14 +514,14 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
     const int64_t npass = nblk * M.args.in_dim;
     const int64_t gmax = (int64_t)ctx->cu_count * (M.nw == 1 ? 4 : 2);
     const int grid = (int)(npass < gmax ? npass : gmax);
-    {   // The primal once per block of rows (mlp_jvp_first_kernel + mlp_jvp_rest_kernel: 1 + floor(dx / 2) passes per block)
+    {   // The primal once per block of rows (mlp_jvp_first_kernel + mlp_jvp_rest_kernel: (1 + dx) / 2 passes per block)
         // or once per direction (mlp_jvp_kernel: dx passes per block): whichever leaves the busiest workgroup fewer
         // passes.  RT_JVP_MASKS=0 (read by rt_ctx_create) keeps the per-direction kernel, =2 forces the other.
-        const int64_t nrest = nblk * (M.args.in_dim / 2);
+        const int64_t nrest = (nblk * (M.args.in_dim - 1) + 1) / 2;
         const int64_t g1 = nblk < gmax ? nblk : gmax, g2 = nrest < gmax ? nrest : gmax;
         const int64_t busiest2 = (nblk + g1 - 1) / g1 + (g2 ? (nrest + g2 - 1) / g2 : 0), busiest1 = (npass + grid - 1) / grid;
         const size_t mask_bytes = (size_t)nblk * (M.n_layers - 1) * 64 * M.nw * sizeof(unsigned long long);
-        if ((ctx->jvp_masks == 1 && M.args.in_dim >= 3 && busiest2 < busiest1 && mask_bytes <= (1ull << 30)) ||
+        if ((ctx->jvp_masks == 1 && M.args.in_dim >= 2 && busiest2 < busiest1 && mask_bytes <= (1ull << 30)) ||
             (ctx->jvp_masks == 2 && M.args.in_dim >= 2)) {
             const int rc = ensure(ctx, ctx->b_mask, mask_bytes);
             if (rc) return rc;
@@ -539,14 +539,14 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
         }
     }
     if (M.nw == 1) {
-        if (M.hid == 64) return launch_jvp<64, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
-        return launch_jvp<128, 1>(ctx, M.args, in, N, yout, J, grid, cv.total);
+        if (M.hid == 64) return launch_jvp<64, 1>(ctx, M, in, N, yout, J, grid, cv.total);
+        return launch_jvp<128, 1>(ctx, M, in, N, yout, J, grid, cv.total);
     }
-    if (M.nw == 2) return launch_jvp<256, 2>(ctx, M.args, in, N, yout, J, grid, cv.total);
+    if (M.nw == 2) return launch_jvp<256, 2>(ctx, M, in, N, yout, J, grid, cv.total);
     switch (M.hid) {
-        case 128: return launch_jvp<128>(ctx, M.args, in, N, yout, J, grid, cv.total);
-        case 256: return launch_jvp<256>(ctx, M.args, in, N, yout, J, grid, cv.total);
-        case 512: return launch_jvp<512>(ctx, M.args, in, N, yout, J, grid, cv.total);
+        case 128: return launch_jvp<128>(ctx, M, in, N, yout, J, grid, cv.total);
+        case 256: return launch_jvp<256>(ctx, M, in, N, yout, J, grid, cv.total);
+        case 512: return launch_jvp<512>(ctx, M, in, N, yout, J, grid, cv.total);
         default: return fail(ctx, RT_EUNSUPPORTED, "hidden width not supported");
     }
 }

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpArgs m, const
 // POINT, not per sample, so it is ~1e-4 of the IS estimate's work).
 // ----------------------------------------------------------------------------------------------
 template <int HID, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const float* in, int64_t N,
+__global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const float* zero_bias, const float* in, int64_t N,
                                                           float* yout, float* J) {
     constexpr int NTHREADS = 64 * NW;
     constexpr int MS = 64;
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const
         Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
         MlpPre<HID, NW> pre;
-        mlp_core<HID, 2, true, NW>(m, pre, x0, act, wave, lane ST_ARG);
+        mlp_prefetch<HID, 2, 1, NW>(m, pre, wave, lane, zero_bias);
+        mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, nullptr, zero_bias);
         if (row < N) {
             if (sl < 32) {
                 if (dir == 0 && yout)
@@ -487,16 +488,17 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_kernel(const MlpArgs m, const
 // The same Jacobian with the primal evaluated ONCE per block of 32 rows instead of once per input direction, as two
 // kernels.  mlp_jvp_first_kernel: one pass per block of rows — mlp_jvp_kernel's pass for direction 0 (primal + tangent e_0) —
 // which also leaves, per hidden layer and thread, the 64-bit mask of its positive primal pre-activations
-// (mask_ws[block of rows][hidden layer][thread]).  mlp_jvp_rest_kernel: the other directions, TWO tangent columns per pass
-// (e_d in sample tile 0, e_{d+1} in tile 1, d = 1, 3, ...), their leaky-ReLU slopes taken from the block's masks — on the
-// fused kernel's skewed layer schedule (rt_mlp.hpp skew_layer, MASKED: tile B two k-groups behind tile A, the mask select
-// as the one VALU cluster per tile), with all-zero hidden biases (m0); passes are dealt one by one like everywhere else.
-// 1 + floor(in_dim / 2) passes per block instead of in_dim: the same MFMA chains on the same operands, so J has the
-// same bits.  (One kernel doing both kinds of pass spilled registers at width 512: the plain and the skewed schedule's
-// live ranges add up.)
+// (mask_ws[block of rows][hidden layer][thread]).  mlp_jvp_rest_kernel: the remaining (block of rows, direction >= 1)
+// items in order, TWO per pass — item 2p in sample tile 0, item 2p+1 in tile 1, each tile's leaky-ReLU slopes taken from
+// its own block's masks (for an even in_dim a pass straddles two blocks of rows) — with all-zero hidden biases (m0).
+// Every pass of all three kernels runs the fused kernel's skewed layer schedule (rt_mlp.hpp skew_layer, JM: tile B two
+// k-groups behind tile A, the mask select / leaky ReLU as the one VALU cluster per tile); passes are dealt one by one
+// like everywhere else.  (1 + in_dim) / 2 passes per block of rows instead of in_dim: the same MFMA chains on the same
+// operands, so J has the same bits.  (One kernel doing both kinds of pass spilled registers at width 512.)
 template <int HID, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void mlp_jvp_first_kernel(const MlpArgs m, const float* in, int64_t N,
-                                                                float* yout, float* J, unsigned long long* mask_ws) {
+__global__ __launch_bounds__(64 * NW) void mlp_jvp_first_kernel(const MlpArgs m, const float* zero_bias, const float* in,
+                                                                int64_t N, float* yout, float* J,
+                                                                unsigned long long* mask_ws) {
     constexpr int NTHREADS = 64 * NW;
     constexpr int MS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -524,7 +526,9 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_first_kernel(const MlpArgs m,
         Stamps st; st.t = 0; for (int i = 0; i < NSTAMP; ++i) st.acc[i] = 0;
 #endif
         MlpPre<HID, NW> pre;
-        mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, mask_ws + (size_t)blk * (m.n_layers - 1) * NTHREADS);
+        mlp_prefetch<HID, 2, 1, NW>(m, pre, wave, lane, zero_bias);
+        mlp_core<HID, 2, 1, NW>(m, pre, x0, act, wave, lane ST_ARG, mask_ws + (size_t)blk * (m.n_layers - 1) * NTHREADS,
+                                zero_bias);
         if (row < N) {
             if (sl < 32) {
                 if (yout)
@@ -551,13 +555,19 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_rest_kernel(const MlpArgs m0,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     for (int i = tid; i < m0.k0 * MS / 4; i += NTHREADS) ((f32x4*)x0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int npair = m0.in_dim / 2;                              // passes per block of rows: directions (1, 2), (3, 4), ...
-    const int64_t npass = ((N + 31) / 32) * npair;
+    const int nd = m0.in_dim - 1;                                  // directions 1 .. in_dim-1 of every block of rows
+    const int64_t nitem = ((N + 31) / 32) * nd;                    // (block, direction) items, two per pass
+    const int64_t npass = (nitem + 1) / 2;
     const int sl = tid & 63, ph = tid >> 6;
+    const size_t mask_stride = (size_t)(m0.n_layers - 1) * NTHREADS;
     for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
-        const int64_t blk = ps / npair;
-        const int mydir = 1 + 2 * (int)(ps - blk * npair) + (sl >> 5);    // this column's direction (== in_dim: an idle tile)
-        const int64_t row = blk * 32 + (sl & 31);
+        const int64_t itA = 2 * ps, blkA = itA / nd;
+        const int dirA = 1 + (int)(itA - blkA * nd);
+        const bool hasB = itA + 1 < nitem;                         // the very last pass of an odd item count: tile 1 idles
+        const int64_t blkB = (dirA < nd || !hasB) ? blkA : blkA + 1;
+        const int dirB = !hasB ? m0.in_dim : (dirA < nd ? dirA + 1 : 1);
+        const int mydir = (sl < 32) ? dirA : dirB;                 // this column's direction (== in_dim: an idle tile)
+        const int64_t row = ((sl < 32) ? blkA : blkB) * 32 + (sl & 31);
         __syncthreads();
         for (int d = ph; d < m0.in_dim; d += NW)
             *(float*)(x0 + act_off<MS>(d >> 3, sl, (d >> 2) & 1) + 4 * (d & 3)) = (d == mydir) ? 1.0f : 0.0f;
@@ -568,7 +578,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_jvp_rest_kernel(const MlpArgs m0,
         MlpPre<HID, NW> pre;
         mlp_prefetch<HID, 2, 2, NW>(m0, pre, wave, lane);
         mlp_core<HID, 2, 2, NW>(m0, pre, x0, act, wave, lane ST_ARG,
-                                const_cast<unsigned long long*>(mask_ws) + (size_t)blk * (m0.n_layers - 1) * NTHREADS);
+                                const_cast<unsigned long long*>(mask_ws) + (size_t)blkA * mask_stride, nullptr,
+                                mask_ws + (size_t)blkB * mask_stride);
         if (row < N && mydir < m0.in_dim)
             for (int d = ph; d < m0.out_dim; d += NW)
                 J[(row * m0.out_dim + d) * m0.in_dim + mydir] = mlp_out_nobias<MS>(m0, part, d, sl);

@@ -88,9 +88,7 @@ __device__ __forceinline__ void lrelu_quad(f32x16& t, int q, float alpha) {
 
 // FIRST: the accumulators are not read — the first k-step takes the constant 0 as C, so a layer needs no
 // accumulator clearing (128 v_accvgpr_write per layer otherwise).
-// JVP = 1: sample tile 1 carries tangent columns (mlp_jvp_kernel), which take no bias.  JVP = 2: both tiles do (the
-// tangent-only passes of mlp_jvp_rest_kernel).
-template <int NFT, int NST, bool FIRST = false, int JVP = 0>
+template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 (&a)[NFT],
                                            const f32x4 (&b)[NST], const f32x16* cinit = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -102,7 +100,7 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[NFT][NST], const f32x4 
             for (int st = 0; st < NST; ++st)
                 acc[ft][st] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                     a[ft][e], b[st][e],
-                    (FIRST && e == 0) ? ((cinit && !(JVP == 2 || (JVP == 1 && st == 1))) ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
+                    (FIRST && e == 0) ? (cinit ? cinit[ft] : zero) : acc[ft][st], 0, 0, 0);
 }
 
 // Source of one wave's packed weights for a layer: a buffer resource (SGPR descriptor) plus the lane's byte offset, so
@@ -142,12 +140,12 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[NFT], f32x4 (&b)[NST], con
 }
 
 // Short / odd K (layer 0: K = padded input dim): no software pipelining.
-template <int NFT, int NST, int JVP = 0>
+template <int NFT, int NST>
 __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const WSrc& wl,
                                                  int ftt, int nkg, const char* bl, const f32x16* cinit) {
     f32x4 a[NFT], b[NST];
     load_group<NFT, NST>(a, b, wl, ftt * 64, bl, 0);
-    mfma_group<NFT, NST, true, JVP>(acc, a, b, cinit);
+    mfma_group<NFT, NST, true>(acc, a, b, cinit);
 #pragma unroll 1
     for (int kg = 1; kg < nkg; ++kg) {
         load_group<NFT, NST>(a, b, wl, ftt * 64, bl, kg);
@@ -159,13 +157,13 @@ __device__ __forceinline__ void gemm_tile_simple(f32x16 (&acc)[NFT][NST], const 
 // of the current one on (ac, bc).  hipcc would otherwise sink every load down to its first use (exposing
 // the LDS / L2 latency once per group): the sched_group_barrier sequence pins "one memory instruction
 // behind each of the first MFMAs", and sched_barrier(0) keeps stages from mixing.
-template <int NFT, int NST, bool FIRST = false, int JVP = 0>
+template <int NFT, int NST, bool FIRST = false>
 __device__ __forceinline__ void pipe_stage(f32x16 (&acc)[NFT][NST], f32x4 (&an)[NFT], f32x4 (&bn)[NST],
                                            const f32x4 (&ac)[NFT], const f32x4 (&bc)[NST],
                                            const WSrc& wl, int wstride, const char* bl, int kgn,
                                            const f32x16* cinit = nullptr) {
     load_group<NFT, NST>(an, bn, wl, wstride, bl, kgn);
-    mfma_group<NFT, NST, FIRST, JVP>(acc, ac, bc, cinit);
+    mfma_group<NFT, NST, FIRST>(acc, ac, bc, cinit);
     constexpr int NM = 4 * NFT * NST;   // MFMAs in the stage
 #pragma unroll
     for (int i = 0; i < NFT; ++i) {
@@ -225,7 +223,7 @@ __device__ __forceinline__ void final_stage_act0(f32x16 (&acc)[NFT][NST], const 
 // MFMAs issue.  Tail prefetches are clamped to the last group (redundant, in bounds).
 // a0..a2 arrive pre-requested (prefetch_a); only the LDS operands of groups 0..2 are read here.
 // ACT0: on return sample tile 0's accumulators already hold lrelu(pre-activation) (see final_stage_act0).
-template <int NFT, int NST, int JVP = 0, bool ACT0 = false>
+template <int NFT, int NST, bool ACT0 = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[NFT], f32x4 (&a1)[NFT],
                                           f32x4 (&a2)[NFT], const WSrc& wl,
                                           int ftt, int nkg, const char* bl, const f32x16* cinit, float alpha = 0.f) {
@@ -240,7 +238,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[NFT][NST], f32x4 (&a0)[N
     }
     __builtin_amdgcn_sched_barrier(0);
     // first four k-groups peeled: their first MFMAs start the accumulators from the constant 0
-    pipe_stage<NFT, NST, true, JVP>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
+    pipe_stage<NFT, NST, true>(acc, a3, b3, a0, b0, wl, wstride, bl, 3, cinit);
     pipe_stage<NFT, NST>(acc, a0, b0, a1, b1, wl, wstride, bl, min(4, lastg));
     pipe_stage<NFT, NST>(acc, a1, b1, a2, b2, wl, wstride, bl, min(5, lastg));
     pipe_stage<NFT, NST>(acc, a2, b2, a3, b3, wl, wstride, bl, min(6, lastg));
@@ -291,64 +289,11 @@ __device__ __forceinline__ void load_bias(f32x16 (&bv)[NFT], const float* __rest
 // fmaf chain  fma(w_kn, x_kn, ... fma(w_k0, x_k0, bias)).
 // C/D map of the 32x32 MFMA: lane (h, j): column j = sample; register r = row (r&3) + 8(r>>2) + 4h = feature.
 // Registers 4q..4q+3 of tile (FT, st) are features 32FT + 8q + 4h + (0..3) = next-layer k-group 4FT+q, half h.
-// JVP (NST == 2): tile 0 holds primal pre-activations t, tile 1 the tangent pre-activations dt of the SAME rows in
-// the same lanes and registers, so the tangent's activation is lrelu'(t) * dt with no cross-lane traffic:
-// slope 1 where t > 0, alpha elsewhere.
 // ACT0: sample tile 0 is already activated (gemm_tile<..., ACT0>); only tile 1's arithmetic is left.
-// mk (JVP = 1, may be null): where this thread leaves the layer's slope mask — bit 16 ft + r set where the primal
-// pre-activation in register r of feature tile ft is > 0 — for the tangent-only passes that follow on the same rows
-// (JVP = 2: both tiles hold tangent pre-activations of the rows whose primal left the mask, in the same lanes and
-// registers, so the slope is again a per-register select; no primal is recomputed).
-template <int NFT, int NST, int JVP = 0, bool ACT0 = false>
-__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane,
-                                          unsigned long long* mk = nullptr) {
+template <int NFT, int NST, bool ACT0 = false>
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NFT][NST], float alpha, char* act, int wave, int lane) {
     constexpr int MS = 32 * NST;
     const int h = lane >> 5, j = lane & 31;
-    if constexpr (JVP == 1) {
-        static_assert(NST == 2 && NFT <= 4, "JVP pairs sample tile 0 (primal) with sample tile 1 (tangent)");
-        unsigned long long mask = 0;
-#pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-            const int FT = wave * NFT + ft;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v0, v1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[ft][0][4 * q + e], dt = acc[ft][1][4 * q + e];
-                    v0[e] = vmax(t, t * alpha);
-                    v1[e] = (t > 0.0f) ? dt : dt * alpha;
-                    if (t > 0.0f) mask |= 1ull << (16 * ft + 4 * q + e);
-                }
-                *(f32x4*)(act + act_off<MS>(4 * FT + q, j, h)) = v0;
-                *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 + j, h)) = v1;
-            }
-        }
-        if (mk) *mk = mask;
-        return;
-    }
-    if constexpr (JVP == 2) {
-        static_assert(NST == 2 && NFT <= 4, "two tangent tiles");
-        const unsigned long long mask = *mk;
-#pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-            const int FT = wave * NFT + ft;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v0, v1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool pos = (mask >> (16 * ft + 4 * q + e)) & 1ull;
-                    const float d0 = acc[ft][0][4 * q + e], d1 = acc[ft][1][4 * q + e];
-                    v0[e] = pos ? d0 : d0 * alpha;
-                    v1[e] = pos ? d1 : d1 * alpha;
-                }
-                *(f32x4*)(act + act_off<MS>(4 * FT + q, j, h)) = v0;
-                *(f32x4*)(act + act_off<MS>(4 * FT + q, 32 + j, h)) = v1;
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
         const int FT = wave * NFT + ft;
@@ -447,6 +392,25 @@ __device__ __forceinline__ void mask_tile(f32x16 (&acc)[NFT][2], float alpha, un
             acc[ft][TILE][r] = ((mask >> (16 * ft + r)) & 1ull) ? d : d * alpha;
         }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// lrelu_tile for the PRIMAL tile of a Jacobian pass (tile 0), which also returns the mask of its positive pre-activations
+// for the tangent tile(s) of the same rows (mask_tile).
+template <int NFT>
+__device__ __forceinline__ unsigned long long lrelu_mask_tile(f32x16 (&acc)[NFT][2], float alpha) {
+    static_assert(NFT <= 4, "64 mask bits per thread and layer");
+    unsigned long long mask = 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t = acc[ft][0][r];
+            if (t > 0.0f) mask |= 1ull << (16 * ft + r);
+            acc[ft][0][r] = vmax(t, t * alpha);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    return mask;
 }
 
 // Bias of one register quad (idx = 4*ft + q) of tile TILE, loaded straight INTO the accumulators: a layer's first MFMA
@@ -578,12 +542,19 @@ __device__ __forceinline__ void skew_edge_stage(f32x16 (&acc)[NFT][2], const f32
 // activations, not yet stored, and every wave is done reading tile B's image.  On return the same holds one layer on
 // (wn / bias_n = the next layer's weights and bias; when there is none the caller passes this layer's again and
 // ignores the result).
-// MASKED (tangent-only passes of the Jacobian kernel): the two clusters select slopes by `mk`, this layer's mask (mask_tile).
-template <int NFT, int NKG, bool MASKED = false>
+// JM (the Jacobian kernels; mkp = this thread's slot for this layer's slope mask): 1 — tile A carries primal rows, tile B
+// tangent columns of the same rows: A's cluster is lrelu_mask_tile (the mask goes to *mkp when mkp is not null), B's is
+// mask_tile with it; `bias` (tile B's) is then an all-zero vector.  2 — both tiles carry tangent columns, of rows whose
+// primal left the mask at *mkp (tile A's rows) and *mkpB (tile B's: the same rows or another block's): both clusters
+// are mask_tile.  0: the forward pass as it always was.
+template <int NFT, int NKG, int JM = 0>
 __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3][NFT], f32x4 (&bA)[6],
                                            const WSrc& wl, const WSrc& wn, const BiasSrc& bias, const BiasSrc& bias_n,
                                            int wstride, const LdsBase& bl, char* st_base, float alpha ST_PARAM,
-                                           unsigned long long mk = 0) {
+                                           unsigned long long* mkp = nullptr,
+                                           const unsigned long long* mkpB = nullptr) {
+    unsigned long long mk = 0, mkB = 0;
+    if constexpr (JM == 2) { mk = *mkp; mkB = *mkpB; }
     static_assert(NKG >= 8, "the next layer's first weights are requested into wh from stage NKG-3 on");
     f32x4 w[6][NFT], bB[6];
     // ---- stage 0: A only; previous layer's tile B stored in the shadow; requests w[3], bA[3] ---------------------
@@ -612,7 +583,9 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     ST(5)
     __syncthreads();   // Q: every wave has read all of tile A's image (its last operand fed stage NKG-1)
     ST(4)
-    if constexpr (MASKED) mask_tile<NFT, 0>(acc, alpha, mk); else lrelu_tile<NFT, 0>(acc, alpha);
+    if constexpr (JM == 1) { mk = lrelu_mask_tile<NFT>(acc, alpha); if (mkp) *mkp = mk; }
+    else if constexpr (JM == 2) mask_tile<NFT, 0>(acc, alpha, mk);
+    else lrelu_tile<NFT, 0>(acc, alpha);
     ST(12)
     // ---- stage NKG: B only; tile A stored in the shadow ------------------------------------------------------
     //      (the next layer's bias goes into tile A's accumulators BLAG quads behind the stores that empty them)
@@ -631,7 +604,9 @@ __device__ __forceinline__ void skew_layer(f32x16 (&acc)[NFT][2], f32x4 (&wh)[3]
     ST(11)
     __syncthreads();   // S: every wave has read all of tile B's image
     ST(4)
-    if constexpr (MASKED) mask_tile<NFT, 1>(acc, alpha, mk); else lrelu_tile<NFT, 1>(acc, alpha);
+    if constexpr (JM == 2) mask_tile<NFT, 1>(acc, alpha, mkB);
+    else if constexpr (JM == 1) mask_tile<NFT, 1>(acc, alpha, mk);
+    else lrelu_tile<NFT, 1>(acc, alpha);
     ST(13)
 }
 
@@ -643,15 +618,18 @@ struct MlpPre {
     f32x16 acc[HID / (32 * NW)][2];
     f32x4 a[HID / (32 * NW)];
 };
+// bias_b (Jacobian passes whose tile 1 carries tangent columns): tile 1's bias vector — all zeros — instead of layer 0's.
 template <int HID, int NW = 4>
-__device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
+__device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane,
+                                              const float* bias_b = nullptr) {
     constexpr int NFT = HID / (32 * NW), FTT = HID / 32;
     const BiasSrc b0 = make_bias(m.bp[0], (32 * wave * NFT + 4 * (lane >> 5)) * 4);
+    const BiasSrc b0b = make_bias(bias_b ? bias_b : m.bp[0], (32 * wave * NFT + 4 * (lane >> 5)) * 4);
     const WSrc w0 = make_wsrc(m.wp[0] + (wave * NFT) * 256, lane);
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) pre.a[ft] = wload(w0, 0, FTT * 64, ft);
 #pragma unroll
-    for (int idx = 0; idx < 4 * NFT; ++idx) { bias_quad<NFT, 0>(pre.acc, b0, idx); bias_quad<NFT, 1>(pre.acc, b0, idx); }
+    for (int idx = 0; idx < 4 * NFT; ++idx) { bias_quad<NFT, 0>(pre.acc, b0, idx); bias_quad<NFT, 1>(pre.acc, b0b, idx); }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -659,10 +637,13 @@ __device__ __forceinline__ void skew_prefetch(const MlpArgs& m, MlpPre<HID, NW>&
 // closing barrier still to come (the caller requests the output layer's weights first).
 // Layer 0 (K = k0, a few k-groups) is the same dance without the skew: all k-groups but the last for both tiles, then
 // the last one: tile A's MFMAs, A's leaky-ReLU cluster, tile B's MFMAs with A's stores behind them, barrier, B's cluster.
-// MASKED: see skew_layer; mask_ws = this workgroup's slope masks, [hidden layer][thread].
-template <int HID, int NW = 4, bool MASKED = false>
+// JM: see skew_layer; mask_ws = the rows' slope masks, [hidden layer][thread] (JM = 1: written, may be null; JM = 2: read,
+// tile A's rows; mask_wsB: tile B's rows); zero_bias (JM = 1): the all-zero bias vector of the tangent tile.
+template <int HID, int NW = 4, int JM = 0>
 __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>& pre, const char* x0, char* act, int wave,
-                                              int lane ST_PARAM, const unsigned long long* mask_ws = nullptr) {
+                                              int lane ST_PARAM, unsigned long long* mask_ws = nullptr,
+                                              const float* zero_bias = nullptr,
+                                              const unsigned long long* mask_wsB = nullptr) {
     constexpr int NFT = HID / (32 * NW), FTT = HID / 32, NKG = HID / 8;
     const int h = lane >> 5, j = lane & 31;
     const int nhid = m.n_layers - 1;
@@ -675,6 +656,7 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>&
     f32x4 wh[3][NFT], bA[6];
     const WSrc w0 = make_wsrc(m.wp[0] + (wave * NFT) * 256, lane);
     WSrc wl = make_wsrc(m.wp[nhid > 1 ? 1 : 0] + (wave * NFT) * 256, lane);
+    unsigned long long mk0 = 0;       // layer 0's slope mask (Jacobian passes only)
     {   // ---- layer 0 (bias and the first weights: skew_prefetch) ----
         f32x4 (&a)[NFT] = pre.a;
         f32x4 bx[2];
@@ -704,7 +686,12 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>&
 #pragma unroll
                 for (int ft = 0; ft < NFT; ++ft) wh[g][ft] = wload(wl, g, FTT * 64, ft);
         }
-        if constexpr (MASKED) mask_tile<NFT, 0>(acc, m.alpha, mask_ws[wave * 64 + lane]);
+        if constexpr (JM == 1) { mk0 = lrelu_mask_tile<NFT>(acc, m.alpha); if (mask_ws) mask_ws[wave * 64 + lane] = mk0; }
+        else if constexpr (JM == 2) {
+            mk0 = mask_ws[wave * 64 + lane];
+            mask_tile<NFT, 0>(acc, m.alpha, mk0);
+            mk0 = mask_wsB[wave * 64 + lane];
+        }
         else lrelu_tile<NFT, 0>(acc, m.alpha);
         // (layer 1's bias goes into tile A's accumulators BLAG quads behind the stores that empty them; harmless if
         // there is no layer 1)
@@ -721,15 +708,17 @@ __device__ __forceinline__ void hidden_skewed(const MlpArgs& m, MlpPre<HID, NW>&
         bA[1] = lds_operand(bl, 2048);
         bA[2] = lds_operand(bl, 4096);
     }
-    if constexpr (MASKED) mask_tile<NFT, 1>(acc, m.alpha, mask_ws[wave * 64 + lane]);
+    if constexpr (JM != 0) mask_tile<NFT, 1>(acc, m.alpha, mk0);
     else lrelu_tile<NFT, 1>(acc, m.alpha);
     ST(1)
     for (int l = 1; l < nhid; ++l) {
         const int ln = (l + 1 < nhid) ? l + 1 : l;
         const WSrc wn = make_wsrc(m.wp[ln] + (wave * NFT) * 256, lane);
-        if constexpr (MASKED)
-            skew_layer<NFT, NKG, true>(acc, wh, bA, wl, wn, make_bias(m.bp[l], bias_voff), make_bias(m.bp[ln], bias_voff),
-                                       FTT * 64, bl, st_base, m.alpha ST_ARG, mask_ws[l * (64 * NW) + wave * 64 + lane]);
+        if constexpr (JM != 0)
+            skew_layer<NFT, NKG, JM>(acc, wh, bA, wl, wn, make_bias(JM == 1 ? zero_bias : m.bp[l], bias_voff),
+                                     make_bias(m.bp[ln], bias_voff), FTT * 64, bl, st_base, m.alpha ST_ARG,
+                                     mask_ws ? mask_ws + l * (64 * NW) + wave * 64 + lane : nullptr,
+                                     JM == 2 ? mask_wsB + l * (64 * NW) + wave * 64 + lane : nullptr);
         else
         skew_layer<NFT, NKG>(acc, wh, bA, wl, wn, make_bias(m.bp[l], bias_voff), make_bias(m.bp[ln], bias_voff),
                              FTT * 64, bl, st_base, m.alpha ST_ARG);
@@ -855,18 +844,23 @@ __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act,
 // (bias not yet added).  Must be called by all 64 * NW threads of the workgroup.
 // pre: see mlp_prefetch (call it for the same pass before mlp_core, as early as the caller can).
 template <int HID, int NST, int JVP = 0>
-constexpr bool mlp_is_skewed() { return (NST == 2) && JVP != 1; }   // 64-sample passes: widths 64, 128, 256, 512; JVP = 2
-                                                                    // (two tangent tiles): the same schedule with mask_tile
+constexpr bool mlp_is_skewed() { return NST == 2; }   // 64-sample passes: widths 64, 128, 256, 512 (the Jacobian passes too)
 
 template <int HID, int NST, int JVP = 0, int NW = 4>
-__device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane) {
-    if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID, NW>(m, pre, wave, lane);
+__device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& pre, int wave, int lane,
+                                             const float* zero_bias = nullptr) {
+    if constexpr (mlp_is_skewed<HID, NST, JVP>()) skew_prefetch<HID, NW>(m, pre, wave, lane, JVP == 1 ? zero_bias : nullptr);
 }
 
-// mask_ws (JVP = 1: optional, JVP = 2: required): this workgroup's slope masks, [hidden layer][thread] (see store_act).
+// JVP (the Jacobian kernels, 64-sample passes only): 1 — sample tile 0 carries primal rows, tile 1 tangent columns of the
+// same rows (zero_bias: the tangent tile's all-zero bias vector; mask_ws, optional: where the rows' slope masks go,
+// [hidden layer][thread]); 2 — both tiles carry tangent columns, their slopes come from mask_ws (tile 0's rows) and
+// mask_wsB (tile 1's rows) and m holds all-zero hidden biases.  See skew_layer.
 template <int HID, int NST, int JVP = 0, int NW = 4>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre, char* x0, char* act, int wave,
-                                         int lane ST_PARAM, unsigned long long* mask_ws = nullptr) {
+                                         int lane ST_PARAM, unsigned long long* mask_ws = nullptr,
+                                         const float* zero_bias = nullptr, const unsigned long long* mask_wsB = nullptr) {
+    static_assert(JVP == 0 || NST == 2, "the Jacobian passes pair two 32-column tiles");
     static_assert(NW == 4 || (NST == 2 && ((NW == 1 && HID <= 128) || (NW == 2 && HID == 256))),
                   "one-wave workgroups: width <= 128; two-wave workgroups: width 256; both on 64-sample passes");
     constexpr int NFT = HID / (32 * NW);
@@ -885,7 +879,7 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
     f32x4 wsm[2 * KQ * NQL];
     constexpr bool SKEWED = mlp_is_skewed<HID, NST, JVP>();
     if constexpr (SKEWED) {
-        if constexpr (JVP == 2) hidden_skewed<HID, NW, true>(m, pre, x0, act, wave, lane ST_ARG, mask_ws);
+        if constexpr (JVP != 0) hidden_skewed<HID, NW, JVP>(m, pre, x0, act, wave, lane ST_ARG, mask_ws, zero_bias, mask_wsB);
         else hidden_skewed<HID, NW>(m, pre, x0, act, wave, lane ST_ARG);
         ST(1)
         if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
@@ -895,10 +889,10 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
         f32x16 acc[NFT][NST];
         f32x16 bv[NFT];
         load_bias<NFT>(bv, m.bp[0], wave, lane);
-        gemm_tile_simple<NFT, NST, JVP>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
+        gemm_tile_simple<NFT, NST>(acc, make_wsrc(m.wp[0] + (wave * NFT) * 256, lane), FTT, m.k0 >> 3,
                                         x0 + act_off<MS>(0, j, h), bv);
         // hidden layers hand sample tile 0 over already activated (final_stage_act0); layer 0 does it here
-        constexpr bool ACT0 = (NST == 2) && !JVP;
+        constexpr bool ACT0 = (NST == 2);
         if constexpr (ACT0) {
 #pragma unroll
             for (int ft = 0; ft < NFT; ++ft)
@@ -912,21 +906,19 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
             prefetch_a<NFT>(a0, a1, a2, wnext, FTT * 64);
             if (l > 0) __syncthreads();   // all waves finished reading layer l's input
             ST(2)
-            store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane,
-                                           mask_ws ? mask_ws + l * (64 * NW) + wave * 64 + lane : nullptr);
+            store_act<NFT, NST, ACT0>(acc, m.alpha, act, wave, lane);
             load_bias<NFT>(bv, m.bp[l + 1], wave, lane);
             ST(3)
             __syncthreads();
             ST(4)
-            gemm_tile<NFT, NST, JVP, ACT0>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv, m.alpha);
+            gemm_tile<NFT, NST, ACT0>(acc, a0, a1, a2, wnext, FTT, HID / 8, act + act_off<MS>(0, j, h), bv, m.alpha);
             ST(5)
         }
         // the last hidden layer's epilogue (kept out of the loop so the output layer's prefetched weights are not
         // live across the hidden layers' K loops)
         if (nhid > 1) __syncthreads();
         ST(2)
-        store_act<NFT, NST, JVP, ACT0>(acc, m.alpha, act, wave, lane,
-                                       mask_ws ? mask_ws + (nhid - 1) * (64 * NW) + wave * 64 + lane : nullptr);
+        store_act<NFT, NST, ACT0>(acc, m.alpha, act, wave, lane);
         if (small_out) small_load_w<KQ, NQL>(m, q0, lane, wsm);
         ST(3)
         __syncthreads();

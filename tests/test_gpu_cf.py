@@ -106,10 +106,11 @@ def test_cf_estimate_dev_blocks_and_edges(make_nets, monkeypatch):
 
 
 @pytest.mark.parametrize("dx,dy,hid", [(2, 2, 512), (3, 6, 512), (5, 9, 512), (8, 21, 512), (20, 90, 512), (8, 21, 64),
-                                       (5, 9, 128), (3, 6, 256)])
+                                       (5, 9, 128), (3, 6, 256), (2, 2, 64), (4, 4, 128), (2, 3, 256), (6, 2, 256)])
 def test_jacobian_with_slope_masks_has_the_same_bits(make_nets, monkeypatch, dx, dy, hid):
     """mlp_jvp_first_kernel + mlp_jvp_rest_kernel (the primal once per block of 32 rows, its leaky-ReLU slopes kept as bit masks for the tangent-only
-    passes that follow) against mlp_jvp_kernel (the primal recomputed per direction) and the C oracle's forward mode in
+    passes that follow, two (block of rows, direction) items per pass — for an even dx a pass straddles two blocks)
+    against mlp_jvp_kernel (the primal recomputed per direction) and the C oracle's forward mode in
     kernel order: G(x) and J bit for bit, on ragged row counts; and the Laplace estimate built on either."""
     if not os.path.exists("/dev/kfd"):
         pytest.skip("no GPU on this machine")
@@ -128,7 +129,7 @@ def test_jacobian_with_slope_masks_has_the_same_bits(make_nets, monkeypatch, dx,
             engines[mode].set_mlp(H, hw, hb)
         og = c_oracle.OracleMlp(gw, gb)
         rng = np.random.RandomState(dx + dy)
-        for n in (1, 31, 32, 33, 100):
+        for n in (1, 31, 32, 33, 65, 100):
             x = (rng.standard_normal((n, dx)) * 1.5).astype(np.float32)
             o0, j0 = engines["0"].mlp_jacobian(G, x)
             o2, j2 = engines["2"].mlp_jacobian(G, x)
@@ -143,13 +144,14 @@ def test_jacobian_with_slope_masks_has_the_same_bits(make_nets, monkeypatch, dx,
             e.close()
 
 
-def test_jacobian_kernel_choice_on_a_large_call(make_nets, monkeypatch):
-    """The default picks the mask kernel where it leaves the busiest workgroup fewer passes (many rows, dx >= 3): 20 000
-    rows at 5/9 — same bits as the per-direction kernel, and as the oracle on a sample of the rows."""
+@pytest.mark.parametrize("dx,dy", [(5, 9), (2, 2)])
+def test_jacobian_kernel_choice_on_a_large_call(make_nets, monkeypatch, dx, dy):
+    """The default picks the mask kernels where they leave the busiest workgroup fewer passes (many rows, dx >= 2): 20 000
+    rows at 5/9 and 2/2 — same bits as the per-direction kernel, and as the oracle on a sample of the rows."""
     if not os.path.exists("/dev/kfd"):
         pytest.skip("no GPU on this machine")
-    gw, gb, hw, hb = make_nets(5, 9)
-    x = (np.random.RandomState(1).standard_normal((20000, 5)) * 1.5).astype(np.float32)
+    gw, gb, hw, hb = make_nets(dx, dy)
+    x = (np.random.RandomState(1).standard_normal((20000, dx)) * 1.5).astype(np.float32)
     res = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("RT_JVP_MASKS", mode)
