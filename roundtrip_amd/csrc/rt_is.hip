@@ -566,8 +566,12 @@ int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_fla
     if (H.args.in_dim != dy || H.args.out_dim != dx)
         return fail(ctx, RT_EINVAL, "H must map G's output dim to G's input dim");
     if (G.nst != 2) return fail(ctx, RT_EUNSUPPORTED, "Jacobian needs hidden width <= 512 (64-column passes)");
-    const int lds = (dx * dx + dy + dx) * (int)sizeof(double);
+    int lds = (dx * dx + dy + dx) * (int)sizeof(double);
     if (lds > LDS_MAX) return fail(ctx, RT_EUNSUPPORTED, "Laplace estimator: dx x dx float64 matrix does not fit the LDS");
+    // cf_finish_kernel keeps the point's Jacobian in LDS as well where that leaves several one-wave workgroups to a CU
+    const bool stage = lds + dx * dy * (int)sizeof(float) <= 40 * 1024;
+    if (stage) lds += dx * dy * (int)sizeof(float);
+    const void* finish = stage ? (const void*)cf_finish_kernel<true> : (const void*)cf_finish_kernel<false>;
     if (N == 0) return RT_OK;
     int64_t per = (int64_t)((256ull << 20) / ((size_t)dx * dy * sizeof(float)));
     if (per > ctx->cf_block_points) per = ctx->cf_block_points;
@@ -581,7 +585,7 @@ int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_fla
     int rc = ensure(ctx, ctx->b_in, (size_t)per * dy * sizeof(float)); if (rc) return rc;
     rc = ensure(ctx, ctx->b_xhat, (size_t)per * dx * sizeof(float)); if (rc) return rc;
     rc = ensure(ctx, ctx->b_fout, (size_t)per * dy * (1 + (size_t)dx) * sizeof(float)); if (rc) return rc;
-    HIPCHK(ctx, allow_lds(ctx, (const void*)cf_finish_kernel, lds));
+    HIPCHK(ctx, allow_lds(ctx, finish, lds));
     const double PI = 3.14159265358979323846;
     // the constants of :382 / :384 as the reference's Python evaluates them
     const double c0 = -(double)dy * log(sqrt(2.0 * PI) * sd_y);
@@ -599,9 +603,13 @@ int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_fla
         rc = fwd_enqueue(ctx, RT_MLP_H, y32, nb, xhat); if (rc) return rc;
         rc = jvp_enqueue(ctx, RT_MLP_G, xhat, nb, gy, J); if (rc) return rc;
         const int64_t gmax = (int64_t)ctx->cu_count * 16;
-        hipLaunchKernelGGL(cf_finish_kernel, dim3((unsigned)(nb < gmax ? nb : gmax)), dim3(64), lds, ctx->stream,
-                           y + n0 * dy, (const float*)xhat, (const float*)gy, (const float*)J, nb, dx, dy, sd_y * sd_y, c0,
-                           lin_scale, log_flag, out + n0);
+        const dim3 fgrid((unsigned)(nb < gmax ? nb : gmax));
+        if (stage)
+            hipLaunchKernelGGL(cf_finish_kernel<true>, fgrid, dim3(64), lds, ctx->stream, y + n0 * dy, (const float*)xhat,
+                               (const float*)gy, (const float*)J, nb, dx, dy, sd_y * sd_y, c0, lin_scale, log_flag, out + n0);
+        else
+            hipLaunchKernelGGL(cf_finish_kernel<false>, fgrid, dim3(64), lds, ctx->stream, y + n0 * dy, (const float*)xhat,
+                               (const float*)gy, (const float*)J, nb, dx, dy, sd_y * sd_y, c0, lin_scale, log_flag, out + n0);
         HIPCHK(ctx, hipGetLastError());
     }
     return RT_OK;
