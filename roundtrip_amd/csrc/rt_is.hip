@@ -553,7 +553,7 @@ int jvp_enqueue(rt_ctx* ctx, int which, const float* in, int64_t N, float* yout,
 
 // The Laplace estimator for N query points whose float64 coordinates sit at y (device): per block of points, in stream
 // order, y -> float32 feed -> H forward (xhat) -> G forward + Jacobian at xhat (mlp_jvp_kernel) -> cf_finish_kernel.
-// The Jacobians never leave the device: a block's (<= 256 MB of float32, N_blk x dy x dx) is written by one kernel and
+// The Jacobians never leave the device: a block's (<= 1 GiB of float32, N_blk x dy x dx) is written by one kernel and
 // read by the next, which at the reference shapes is < 0.5 % of the Jacobian kernel's own time (YearPredictionMSD 20/90:
 // 7.2 KB per point against 22 generator rows x 4.8 MFLOP).  Buffers are sized once, before anything is enqueued.
 int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_flag, double* out) {
@@ -573,10 +573,10 @@ int cf_enqueue(rt_ctx* ctx, const double* y, int64_t N, double sd_y, int log_fla
     if (stage) lds += dx * dy * (int)sizeof(float);
     const void* finish = stage ? (const void*)cf_finish_kernel<true> : (const void*)cf_finish_kernel<false>;
     if (N == 0) return RT_OK;
-    int64_t per = (int64_t)((256ull << 20) / ((size_t)dx * dy * sizeof(float)));
+    int64_t per = (int64_t)((1ull << 30) / ((size_t)dx * dy * sizeof(float)));
     if (per > ctx->cf_block_points) per = ctx->cf_block_points;
-    {   // ... and <= 256 MB of the Jacobian kernels' slope masks (8 B per thread and hidden layer for every 32 rows)
-        const int64_t per_mask = (int64_t)((256ull << 20) / ((size_t)(G.n_layers - 1) * 64 * G.nw * sizeof(unsigned long long))) * 32;
+    {   // ... and <= 1 GiB of the Jacobian kernels' slope masks (8 B per thread and hidden layer for every 32 rows)
+        const int64_t per_mask = (int64_t)((1ull << 30) / ((size_t)(G.n_layers - 1) * 64 * G.nw * sizeof(unsigned long long))) * 32;
         if (per > per_mask) per = per_mask;
     }
     per &= ~(int64_t)31;                       // whole 32-row blocks of the Jacobian kernel
