@@ -186,6 +186,12 @@ int rt_draw_samples(rt_ctx* ctx, const float* xhat, int64_t N, int64_t y_index_b
  * Replaces numpy's MT19937 behind np.random.chisquare / multivariate_normal (main_density_est.py:267,316-317). */
 int rt_philox4x32_10(rt_ctx* ctx, const uint32_t* ctr_key, int64_t n, uint32_t* out);
 
+/* Diagnostic: out[i] = log(1 + a[i]) for a[i] >= 0 (+inf -> +inf, NaN -> NaN) as the fused kernels' scorer evaluates the
+ * Student-t proposal's log1p(u^2 / df) (scipy.stats.t.logpdf inside w_likelihood_ratio,
+ * /root/reference/main_density_est.py:301-305): the device function itself (even i: inlined; odd i: behind a call, the two
+ * forms the kernels use), for accuracy tests against libm.  Host arrays; synchronous. */
+int rt_log1p_pos(rt_ctx* ctx, const double* a, int64_t n, double* out);
+
 /* Device-resident variant of rt_is_estimate: y_dev, xhat_dev, out_dev are DEVICE pointers on the
  * context's device.  Enqueues on the context's stream and returns without waiting; call rt_sync()
  * before reading out_dev from another stream or the host. */

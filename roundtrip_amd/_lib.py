@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_is_estimate", "rt_is_estimate_multi", "rt_is_estimate_given_samples", "rt_draw_samples", "rt_is_estimate_dev",
     "rt_mlp_forward_dev", "rt_sync", "rt_get_counters", "rt_reset_counters", "rt_device_cu_count",
     "rt_is_pair_count", "rt_is_pairs", "rt_is_merge_pairs", "rt_is_estimate_dev_noalloc",
-    "rt_philox4x32_10", "rt_crc32c", "rt_get_xcd_shares",
+    "rt_philox4x32_10", "rt_log1p_pos", "rt_crc32c", "rt_get_xcd_shares",
     "rt_dev_alloc", "rt_dev_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_dev_mem_info",
     "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_comm_info", "rt_comm_all_gather_f64",
     "rt_comm_all_gather_f64_dev", "rt_comm_all_reduce_max_f64", "rt_comm_barrier",
@@ -83,6 +83,7 @@ def load():
     lib.rt_is_merge_pairs.argtypes = [vp, vp, i64, i64, C.c_int, i64, C.c_int, vp]
     lib.rt_is_estimate_dev_noalloc.argtypes = lib.rt_is_estimate_dev.argtypes
     lib.rt_philox4x32_10.argtypes = [vp, vp, i64, vp]
+    lib.rt_log1p_pos.argtypes = [vp, vp, i64, vp]
     lib.rt_get_xcd_shares.argtypes = [vp, C.POINTER(C.c_double)]
     lib.rt_crc32c.restype = C.c_uint32
     lib.rt_crc32c.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
@@ -316,6 +317,13 @@ class Engine(object):
         ck = np.ascontiguousarray(ctr_key, dtype=np.uint32).reshape(-1, 6)
         out = np.empty((ck.shape[0], 4), dtype=np.uint32)
         self._chk(self._lib.rt_philox4x32_10(self._h, ck.ctypes.data, ck.shape[0], out.ctypes.data))
+        return out
+
+    def log1p_pos(self, a):
+        """log(1 + a), a >= 0, as the scorer evaluates it on the device (diagnostic, for accuracy tests)."""
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        out = np.empty_like(a)
+        self._chk(self._lib.rt_log1p_pos(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
         return out
 
     # ---- device-resident entry points (pointers are raw device addresses, e.g. torch .data_ptr()) ----

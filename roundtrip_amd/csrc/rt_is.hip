@@ -1207,6 +1207,24 @@ int rt_philox4x32_10(rt_ctx* ctx, const uint32_t* ctr_key, int64_t n, uint32_t* 
     return RT_OK;
 }
 
+int rt_log1p_pos(rt_ctx* ctx, const double* a, int64_t n, double* out) {
+    if (!ctx) return RT_EINVAL;
+    if (n < 0) return fail(ctx, RT_EINVAL, "n < 0");
+    if (n == 0) return RT_OK;
+    if (!a || !out) return fail(ctx, RT_EINVAL, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * sizeof(double);
+    int rc = ensure(ctx, ctx->b_in, nb); if (rc) return rc;
+    rc = ensure(ctx, ctx->b_fout, nb); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_in.p, a, nb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(log1p_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)ctx->b_in.p, n, (double*)ctx->b_fout.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_fout.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_sync(rt_ctx* ctx) {
     if (!ctx) return RT_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -104,6 +104,50 @@ __device__ __forceinline__ double wave_sum(double v) {
     return read_lane63(v);
 }
 
+// log(1 + a) for a >= 0 (+inf -> +inf, NaN -> NaN): the Student-t proposal's log1p(u^2 / df), once per latent dim and sample
+// (scipy.stats.t.logpdf, main_density_est.py:301-305).  The device library's log1p covers negative arguments, denormal
+// results and every rounding corner in ~105 float64 instructions; the narrow generators' passes are bound by exactly this
+// kind of per-sample vector work (fp32 MFMA and VALU exclude each other), so the scorer carries its own, ~45 instructions:
+//   1 + a = w + c exactly (w the rounded sum, c its rounding error);  w = m 2^e, m in [sqrt(1/2), sqrt(2));
+//   log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716: 2 s (1 + z/3 + z^2/5 + ... + z^10/21), z = s^2 (next term < 1e-18);
+//   log(1 + a) = e ln 2 + log m + c / w  (c / w: the first-order term of the rounding error; the second is < 2^-106).
+// The quotient s comes from a reciprocal seed refined twice and one residual correction; c / w from a seed refined once.
+// <= 2 ulp (3.4e-16 relative) against long-double log1p over 2e7 arguments in [1e-304, 1e304] (the same arithmetic on the
+// host, scripts/log1p_check.c; on the device: rt_log1p_pos, tests/test_gpu_parity.py).  No contraction beyond the fmas
+// written here: every instantiation of the fused kernel computes the same bits.
+__device__ __forceinline__ double log1p_pos(double a) {
+#pragma clang fp contract(off)
+    const double w = 1.0 + a;
+    const double c = (a >= 1.0) ? 1.0 - (w - a) : a - (w - 1.0);
+    double m = __builtin_amdgcn_frexp_mant(w);                     // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(w);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double r = (double)__builtin_amdgcn_rcpf((float)d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    double s = f * r;
+    s = __builtin_fma(r, __builtin_fma(-d, s, f), s);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);  p = __builtin_fma(p, z, 1.0 / 5.0);  p = __builtin_fma(p, z, 1.0 / 3.0);
+    double rw = (double)__builtin_amdgcn_rcpf((float)w);           // 0 beyond float's range: c / w is far below an ulp there
+    rw = __builtin_fma(rw, __builtin_fma(-w, rw, 1.0), rw);
+    const double ed = (double)e, s2 = s + s;
+    const double res = __builtin_fma(ed, 6.93147180369123816490e-01, s2) +
+                       (__builtin_fma(s2 * z, p, ed * 1.90821492927058770002e-10) + c * rw);
+    return (a <= 1.7976931348623157e308) ? res : a;
+}
+// The same function behind a call: the four-wave kernels' register allocation inside the MLP is sensitive to the size of the
+// scorer that follows it (inlined there, the 512-wide SHARE kernel lost 0.7 %); they score two to five dims per thread and
+// pass, so the call costs them nothing measurable.  Same instructions, same bits.
+__device__ __attribute__((noinline)) double log1p_pos_call(double a) { return log1p_pos(a); }
+
 // One workgroup per CU, up to 512 registers per wave.  NST = 2: 64 samples per pass (hidden width <= 512).
 // NST = 1: 32 samples per pass, used for hidden width 1024, whose 64-sample activation image (256 KB)
 // would not fit in LDS.
@@ -265,7 +309,9 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
                 if (GIVEN) x = valid ? a.xs[((size_t)n_c * a.S + sl.si) * dx + d] : 0.0;
                 else x = (double)*(const float*)(x0 + act_off<MS>(d >> 3, s, (d >> 2) & 1) + 4 * (d & 3));
                 const double u = ((double)centre[d] - x) * a.inv_scale;
-                lw += a.half_dfp1 * log1p(u * u * a.inv_df) - 0.5 * x * x;
+                double l1p;
+                if constexpr (NW == 4) l1p = log1p_pos_call(u * u * a.inv_df); else l1p = log1p_pos(u * u * a.inv_df);
+                lw += a.half_dfp1 * l1p - 0.5 * x * x;
             }
         };
 #pragma unroll
@@ -817,6 +863,10 @@ __global__ void draw_samples_kernel(SamplerArgs sa, const float* xhat, int64_t N
 
 // The raw generator of the sampler on caller-chosen (counter, key) words: in[6t..6t+5] = c0 c1 c2 c3 k0 k1,
 // out[4t..4t+3] = philox4x32_10(...).  For the known-answer test against the published Random123 vectors.
+__global__ void log1p_pos_kernel(const double* in, int64_t n, double* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (t & 1) ? log1p_pos_call(in[t]) : log1p_pos(in[t]);     // both forms the fused kernels use
+}
 __global__ void philox_kernel(const uint32_t* in, int64_t n, uint32_t* out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;

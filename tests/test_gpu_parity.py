@@ -968,3 +968,29 @@ def test_shapes_beyond_the_lds_budget_are_refused(engine):
         assert np.array_equal(fresh.mlp_forward(G, z(3, 2)), z(3, 2))
     finally:
         fresh.close()
+
+
+def test_scorer_log1p_against_libm(engine):
+    """The scorer's own log(1 + a) (rt_kernels.hpp log1p_pos, ~45 float64 instructions instead of the device library's
+    ~105) against numpy's log1p — libm, < 1 ulp — on the arguments the Student-t proposal produces and far beyond:
+    <= 3 ulp of the result everywhere (measured: 2 against long double on the host, scripts/log1p_check.c), exact at 0,
+    below 2^-53 and at +inf, NaN carried."""
+    rng = np.random.RandomState(11)
+    a = np.concatenate([
+        np.exp(rng.uniform(-700, 700, 400000)), rng.uniform(0, 3, 400000), np.exp(rng.uniform(-40, 40, 400000)),
+        np.ldexp(1.0 + rng.uniform(-1e-6, 1e-6, 200000), rng.randint(-100, 100, 200000)),
+        [0.0, 5e-324, 1e-310, 2.2250738585072014e-308, 1e-17, 2.0 ** -53, 2.0 ** -52, np.sqrt(2.0) - 1.0, 1.0, 1.0 - 2.0 ** -53,
+         3.0, 1e154, 1e300, np.finfo(np.float64).max]])
+    got = engine.log1p_pos(a)
+    want = np.log1p(a)
+    ulp = np.spacing(np.abs(want))
+    err = np.abs(got - want) / ulp
+    assert err.max() <= 3.0, (err.max(), a[err.argmax()])
+    tiny = a < 2.0 ** -54
+    assert np.array_equal(got[tiny], a[tiny])
+    sp = engine.log1p_pos(np.array([np.inf, np.nan, 0.0]))
+    assert sp[0] == np.inf and np.isnan(sp[1]) and sp[2] == 0.0
+    # odd and even positions run the two forms the kernels use (behind a call / inlined): same bits
+    b = np.repeat(a[:100000], 2)
+    g2 = engine.log1p_pos(b)
+    assert np.array_equal(g2[0::2], g2[1::2])
