@@ -42,10 +42,11 @@ static double ulp_err(double got, double want) {
     double u = nextafter(fabs(want), INFINITY) - fabs(want);
     return fabs(got - want) / u;
 }
-int main() {
+int main(int argc, char** argv) {
+    const int count = argc > 1 ? atoi(argv[1]) : 20000000;
     double worst = 0, worst_a = 0, worst_rel = 0; srand48(1);
     long n = 0;
-    for (int i = 0; i < 20000000; ++i) {
+    for (int i = 0; i < count; ++i) {
         double a;
         int k = i % 4;
         if (k == 0) a = exp((drand48() * 2 - 1) * 700);
@@ -63,5 +64,5 @@ int main() {
     printf("n %ld worst %.3f ulp at a = %.17g, worst rel %.3g\n", n, worst, worst_a, worst_rel);
     double sp[] = {0.0, 5e-324, 1e-310, 2.2250738585072014e-308, 1e-17, 1.1102230246251565e-16, 2.220446049250313e-16, 0.41421356237309503, 0.41421356237309515, 1.0, 0.99999999999999989, 3.0, 1e154, 1.3407807929942596e154, 1e300, 1.7976931348623157e308, INFINITY, NAN};
     for (unsigned i = 0; i < sizeof sp / sizeof *sp; ++i) printf("a = %-24.17g mine %-24.17g libm %-24.17g  %.2f ulp\n", sp[i], log1p_pos(sp[i]), log1p(sp[i]), ulp_err(log1p_pos(sp[i]), log1p(sp[i])));
-    return 0;
+    return worst <= 2.5 ? 0 : 1;
 }

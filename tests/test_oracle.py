@@ -290,3 +290,22 @@ def test_oracle_gamma_path_statistics(df):
     for d in range(2):
         assert stats.kstest(xs[:, d], stats.t(df).cdf).pvalue > 1e-3
     assert stats.kstest((xs ** 2).sum(axis=1) / 2.0, stats.f(2, df).cdf).pvalue > 1e-3
+
+
+def test_scorer_log1p_algorithm_on_the_host(tmp_path):
+    """The fused kernels' scorer evaluates log(1 + a) with its own float64 routine (rt_kernels.hpp log1p_pos); the same
+    operations in the same order, compiled for the host without contraction, stay within 2.5 ulp of long-double log1pl
+    over 2e6 arguments in [1e-304, 1e304] and agree with libm at the corner cases (scripts/log1p_check.c exits non-zero
+    otherwise).  The device function itself is checked by tests/test_gpu_parity.py::test_scorer_log1p_against_libm."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "log1p_check")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "scripts", "log1p_check.c"), "-lm"])
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    lines = out.stdout.splitlines()
+    assert "worst" in lines[0]
+    for ln in lines[1:]:
+        a = ln.split()[2]
+        if a not in ("nan",):
+            assert float(ln.split("ulp")[0].split()[-1]) <= 1.0, ln
