@@ -28,6 +28,7 @@
 #include <vector>
 #include <new>
 #include <mutex>
+#include <type_traits>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 (573 MB) is dlopen'ed by rt_comm_init, never linked
 

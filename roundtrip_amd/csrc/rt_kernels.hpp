@@ -314,20 +314,69 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
                 lw += a.half_dfp1 * l1p - 0.5 * x * x;
             }
         };
+        [[maybe_unused]] double se_r = 0.0, lw_r = 0.0;   // one-wave workgroups: the sample's sums over all dims, in registers
+        if constexpr (PPT == NPH) {
+            // One-wave workgroups: the thread owns all NPH phases of its sample, so it walks the dims ONCE in ascending
+            // order, dim d into phase d % NPH's accumulator — every phase still adds its dims ph, ph + NPH, ... in
+            // ascending order — eight dims at a time with every LDS read of the eight ahead of the first use, and adds
+            // the phases in phase order in registers: no LDS round trip of the phase sums, no barrier.  Same bits.
+            static_assert(NPH == 4, "64-sample passes");
+            double se[NPH] = {0.0, 0.0, 0.0, 0.0}, lw[NPH] = {0.0, 0.0, 0.0, 0.0};
+            auto score_all = [&](const auto* yrow, const auto* centre) __attribute__((always_inline)) {
+                auto chunk = [&](auto ch, const int d, const int cnt) __attribute__((always_inline)) {   // d % 4 == 0
+                    constexpr int CH = decltype(ch)::value;
+                    float g[CH];
+                    double yv[CH];
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int ph = p + q * NP;
-            double se = 0.0, lw = 0.0;
-            if (!left) score((const double*)yb, (const float*)xh, ph, se, lw);
-            else score(a.y + n_c * dy, a.xhat + n_c * dx, ph, se, lw);
-            scr[ph * MS + s] = se;
-            scr[NPH * MS + ph * MS + s] = lw;
+                    for (int i = 0; i < CH; ++i) {
+                        const bool on = i < cnt;
+                        g[i] = on ? mlp_out_nobias<MS>(m, part, d + i, s) + ob[d + i] : 0.0f;
+                        yv[i] = on ? (double)yrow[d + i] : 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (i < cnt) { const double diff = yv[i] - (double)g[i]; se[i & 3] += diff * diff; }
+                };
+                int d = 0;
+                for (; d + 8 <= dy; d += 8) chunk(std::integral_constant<int, 8>{}, d, 8);
+                if (d + 4 <= dy) { chunk(std::integral_constant<int, 4>{}, d, 4); d += 4; }
+                if (d < dy) chunk(std::integral_constant<int, 4>{}, d, dy - d);
+                for (int d4 = 0; d4 < dx; d4 += 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int dd = d4 + i;
+                        if (dd < dx) {
+                            double x;
+                            if (GIVEN) x = valid ? a.xs[((size_t)n_c * a.S + sl.si) * dx + dd] : 0.0;
+                            else x = (double)*(const float*)(x0 + act_off<MS>(dd >> 3, s, (dd >> 2) & 1) + 4 * (dd & 3));
+                            const double u = ((double)centre[dd] - x) * a.inv_scale;
+                            const double l1p = log1p_pos(u * u * a.inv_df);
+                            lw[i] += a.half_dfp1 * l1p - 0.5 * x * x;
+                        }
+                    }
+                }
+            };
+            if (!left) score_all((const double*)yb, (const float*)xh);
+            else score_all(a.y + n_c * dy, a.xhat + n_c * dx);
+            se_r = ((se[0] + se[1]) + se[2]) + se[3];
+            lw_r = ((lw[0] + lw[1]) + lw[2]) + lw[3];
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const int ph = p + q * NP;
+                double se = 0.0, lw = 0.0;
+                if (!left) score((const double*)yb, (const float*)xh, ph, se, lw);
+                else score(a.y + n_c * dy, a.xhat + n_c * dx, ph, se, lw);
+                scr[ph * MS + s] = se;
+                scr[NPH * MS + ph * MS + s] = lw;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- D. this pass's log-sum-exp pairs (wave 0; lane = sample slot) ----------------------
         if (wave == 0) {
             double se_t = 0.0, lw_t = 0.0;
-            if (lane < MS) {
+            if constexpr (PPT == NPH) { se_t = se_r; lw_t = lw_r; }
+            else if (lane < MS) {
                 se_t = scr[lane]; lw_t = scr[NPH * MS + lane];
 #pragma unroll
                 for (int qq = 1; qq < NPH; ++qq) { se_t += scr[qq * MS + lane]; lw_t += scr[NPH * MS + qq * MS + lane]; }
