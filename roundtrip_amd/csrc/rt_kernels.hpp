@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
         __syncthreads();
         ST(0)
         // ---- B. G forward ---------------------------------------------------------------------
-        mlp_core<HID, NST, false, NW>(m, pre, x0, act, wave, lane ST_ARG);
+        mlp_core<HID, NST, false, NW, NW == 1>(m, pre, x0, act, wave, lane ST_ARG);   // one wave: quarter sums added in registers
         // ---- C. score: thread (s, p) handles dims d = p, p+NP, ... -----------------------------
         int s2 = s;
         asm volatile("" : "+v"(s2));
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW) void is_fused_kernel(const IsArgs a) {
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
                         const bool on = i < cnt;
-                        g[i] = on ? mlp_out_nobias<MS>(m, part, d + i, s) + ob[d + i] : 0.0f;
+                        g[i] = on ? mlp_out_nobias<MS, 1>(m, part, d + i, s) + ob[d + i] : 0.0f;
                         yv[i] = on ? (double)yrow[d + i] : 0.0;
                     }
 #pragma unroll

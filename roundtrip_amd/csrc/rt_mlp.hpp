@@ -774,7 +774,7 @@ __device__ __forceinline__ void small_load_w(const MlpArgs& m, int q0, int lane,
     for (int i = 0; i < 2 * KQ * NQL; ++i) w[i] = wp[i * 4];
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KQ, int NQL = 1, int NQW = NQL>
+template <int KQ, int NQL = 1, int NQW = NQL, bool SUMQ = false>
 __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (&w)[2 * KQ * NQL], char* act, float* part,
                                                  int q0, int lane) {
     constexpr int MS = 64;
@@ -793,6 +793,17 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
     }
     __syncthreads();   // every wave is done reading the activation image
     const int od = m.out_dim;
+    if constexpr (SUMQ) {   // one wave holds every quarter: ((p0 + p1) + p2) + p3 here, one slot (the empty quarters' +0 left out)
+        static_assert(NQW == 4, "SUMQ: one-wave workgroups");
+        f32x4 sum = acc[0];
+#pragma unroll
+        for (int q = 1; q < NQL; ++q) sum += acc[q];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < od) part[d * MS + lane] = sum[d];
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NQL; ++q)
 #pragma unroll
@@ -811,7 +822,7 @@ __device__ __forceinline__ void last_layer_small(const MlpArgs& m, const f32x4 (
 // Output layer of the one- and two-wave workgroups (NW = 1, 2), out_dim <= 32: this wave's NQL non-empty K-quarters one
 // after the other, each its own accumulator chain on a 32-feature tile x 2 sample tiles, all kept in registers until
 // every operand has been read (part aliases the activation image); its empty quarters are written as +0.
-template <int KQ, int NQL, int NQW>
+template <int KQ, int NQL, int NQW, bool SUMQ = false>
 __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act, float* part, int q0, int lane) {
     constexpr int MS = 64;
     const int h = lane >> 5, j = lane & 31;
@@ -825,6 +836,22 @@ __device__ __forceinline__ void last_layer_quarters(const MlpArgs& m, char* act,
     }
     __syncthreads();   // every operand has been read (one wave: just the LDS fence)
     const int od = m.out_dim;
+    if constexpr (SUMQ) {   // one wave holds every quarter: ((p0 + p1) + p2) + p3 here, one slot (the empty quarters' +0 left out)
+        static_assert(NQW == 4, "SUMQ: one-wave workgroups");
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x16 sum = acc[0][0][st];
+#pragma unroll
+            for (int q = 1; q < NQL; ++q) sum += acc[q][0][st];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (d < od) part[d * MS + 32 * st + j] = sum[r];
+            }
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -856,11 +883,14 @@ __device__ __forceinline__ void mlp_prefetch(const MlpArgs& m, MlpPre<HID, NW>& 
 // same rows (zero_bias: the tangent tile's all-zero bias vector; mask_ws, optional: where the rows' slope masks go,
 // [hidden layer][thread]); 2 — both tiles carry tangent columns, their slopes come from mask_ws (tile 0's rows) and
 // mask_wsB (tile 1's rows) and m holds all-zero hidden biases.  See skew_layer.
-template <int HID, int NST, int JVP = 0, int NW = 4>
+// SUMQ (one-wave workgroups only; the fused kernel's choice): the output layer's four quarter sums are added in registers
+// and only the sum goes to LDS — read it with mlp_out<MS, 1>.
+template <int HID, int NST, int JVP = 0, int NW = 4, bool SUMQ = false>
 __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre, char* x0, char* act, int wave,
                                          int lane ST_PARAM, unsigned long long* mask_ws = nullptr,
                                          const float* zero_bias = nullptr, const unsigned long long* mask_wsB = nullptr) {
     static_assert(JVP == 0 || NST == 2, "the Jacobian passes pair two 32-column tiles");
+    static_assert(!SUMQ || NW == 1, "SUMQ: the wave must own all four quarters");
     static_assert(NW == 4 || (NST == 2 && ((NW == 1 && HID <= 128) || (NW == 2 && HID == 256))),
                   "one-wave workgroups: width <= 128; two-wave workgroups: width 256; both on 64-sample passes");
     constexpr int NFT = HID / (32 * NW);
@@ -926,12 +956,12 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
     }
     float* part = (float*)act;
     if (small_out) {
-        last_layer_small<KQ, NQL, NQW>(m, wsm, act, part, q0, lane);
+        last_layer_small<KQ, NQL, NQW, SUMQ>(m, wsm, act, part, q0, lane);
         ST(6)
         return;
     }
     if constexpr (NW != 4) {
-        last_layer_quarters<KQ, NQL, NQW>(m, act, part, q0, lane);   // out_dim <= 32 (rt_set_mlp)
+        last_layer_quarters<KQ, NQL, NQW, SUMQ>(m, act, part, q0, lane);   // out_dim <= 32 (rt_set_mlp)
         ST(6)
         return;
     }
@@ -944,15 +974,18 @@ __device__ __forceinline__ void mlp_core(const MlpArgs& m, MlpPre<HID, NW>& pre,
     ST(6)
 }
 
-template <int MS>
+// NQ = 1 (mlp_core<..., SUMQ = true>): the one wave that computed all four quarters added them in registers, in this
+// order, and left the sum in slot 0.
+template <int MS, int NQ = 4>
 __device__ __forceinline__ float mlp_out_nobias(const MlpArgs& m, const float* part, int d, int s) {
     const int od = m.out_dim;
+    if constexpr (NQ == 1) return part[d * MS + s];
     const float p0 = part[(0 * od + d) * MS + s], p1 = part[(1 * od + d) * MS + s];
     const float p2 = part[(2 * od + d) * MS + s], p3 = part[(3 * od + d) * MS + s];
     return ((p0 + p1) + p2) + p3;
 }
-template <int MS>
+template <int MS, int NQ = 4>
 __device__ __forceinline__ float mlp_out(const MlpArgs& m, const float* part, int d, int s) {
-    return mlp_out_nobias<MS>(m, part, d, s) + m.bp[m.n_layers - 1][d];
+    return mlp_out_nobias<MS, NQ>(m, part, d, s) + m.bp[m.n_layers - 1][d];
 }
 
